@@ -1,0 +1,348 @@
+// Flash-attention forward for gfx950: dense softmax(Q K^T * scale) V, bf16
+// in/out, fp32 scores/softmax/accumulation, online softmax over 64-key tiles.
+//
+// Shape of the computation (one workgroup = 4 wavefronts = 128 query rows of
+// one (batch, head); each wavefront owns 32 query rows):
+//   S^T[key][q] = mfma_32x32x16(A = K tile fragment, B = Q fragment)
+//       -> the query sits on the LANE, the keys in registers, so the row max /
+//          row sum are in-register reductions plus ONE exchange between lane l
+//          and lane l+32; no LDS round trip for softmax.
+//   O^T[dv][q] += mfma_32x32x16(A = V^T fragment, B = P^T)
+//       -> P^T is the S^T accumulator itself (converted to bf16 in place): an
+//          accumulator tile is a valid B operand of the next MFMA with no lane
+//          movement; m, l and the O rescale all stay lane-local.
+// Memory: Q straight to registers (coalesced 16-byte loads, once); K and V
+// tiles HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered,
+// one barrier per tile.  K is read row-wise (ds_read_b128) with the chunk
+// index XORed by (key & 15); V is read column-wise with the hardware transpose
+// read ds_read_b64_tr_b16 from a row-major image whose chunk index is XORed by
+// ((key&3)<<2 | (key>>2)&3): both reads are bank-conflict free.  LDS-DMA
+// writes lane-linearly, so the same XOR is applied to each lane's SOURCE
+// address.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct AttnParams {
+  const unsigned short* q;
+  const unsigned short* k;
+  const unsigned short* v;
+  unsigned short* o;
+  float* lse;
+  int B, Sq, Sk, H, Hk;
+  int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
+  float scale_log2;  // softmax_scale * log2(e)
+};
+
+__device__ __forceinline__ int k_swz(int key) { return key & 15; }
+__device__ __forceinline__ int v_swz(int key) { return ((key & 3) << 2) | ((key >> 2) & 3); }
+
+// D = head size (128 or 64).  KV tile = 64 keys.
+template <int D, bool TRREAD>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+  constexpr int KV = 64;
+  constexpr int ROWB = D * 2;                // bytes per K/V row
+  constexpr int CPR = ROWB / 16;             // 16-B chunks per row (16 or 8)
+  constexpr int TILE_BYTES = KV * ROWB;      // one K or V tile
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int PIECES = 2 * TILE_BYTES / 1024 / 4;  // 1-KiB DMA pieces per wave per stage
+  constexpr int KSTEPS = D / 16;             // QK^T k-steps
+  constexpr int DVB = D / 32;                // 32-wide dv blocks
+  static_assert(D == 128 || D == 64, "head size");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int hh = lane >> 5;
+
+  // grid: x = q block (fastest), y = head, z = batch.  Consecutive blocks share
+  // (b, h), i.e. the same K/V, which keeps K/V re-reads in L2.
+  const int qb = blockIdx.x;
+  const int head = blockIdx.y;
+  const int b = blockIdx.z;
+  const int hk = head / (p.H / p.Hk);
+  const int q0 = qb * 128 + wave * 32;
+
+  // ---- Q fragments: B operand, lane -> query row r, d = 16s + 8hh + 0..7 ----
+  bf16x8 qf[KSTEPS];
+  {
+    int qrow = q0 + r;
+    if (qrow >= p.Sq) qrow = p.Sq - 1;
+    const unsigned short* qp = p.q + b * p.q_sb + (int64_t)qrow * p.q_ss + head * p.q_sh;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+      qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * hh);
+  }
+
+  // ---- LDS-DMA sources: piece = 1 KiB = 1024/ROWB rows; [K tile | V tile] ----
+  const unsigned short* kbase = p.k + b * p.k_sb + hk * p.k_sh;
+  const unsigned short* vbase = p.v + b * p.v_sb + hk * p.v_sh;
+  constexpr int ROWS_PER_PIECE = 1024 / ROWB;  // 4 (D=128) or 8 (D=64)
+  // per piece: which tile (K or V), row in tile, logical chunk for this lane
+  int prow[PIECES];
+  int pchunk[PIECES];
+  bool pisv[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int piece = wave + 4 * i;             // 0 .. 2*TILE_BYTES/1024-1
+    const int lin = piece * 64 + lane;          // 16-B slot index in [K|V] stage image
+    const int slot = lin % (TILE_BYTES / 16);   // slot within its tile
+    pisv[i] = lin >= TILE_BYTES / 16;
+    const int row = slot / CPR;
+    const int pc = slot % CPR;
+    prow[i] = row;
+    pchunk[i] = pisv[i] ? (pc ^ (v_swz(row) & (CPR - 1))) : (pc ^ (k_swz(row) & (CPR - 1)));
+  }
+  (void)ROWS_PER_PIECE;
+
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int piece = wave + 4 * i;
+      int key = k0 + prow[i];
+      if (key >= p.Sk) key = p.Sk - 1;
+      const unsigned short* src = pisv[i] ? vbase + (int64_t)key * p.v_ss + pchunk[i] * 8
+                                          : kbase + (int64_t)key * p.k_ss + pchunk[i] * 8;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
+                                       (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16, 0,
+                                       0);
+    }
+  };
+
+  // ---- per-lane LDS read offsets ----------------------------------------------
+  // K row read (A operand): row = 32*kb + r, chunk = 2s + hh
+  int koff[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s)
+    koff[s] = r * ROWB + (((2 * s + hh) ^ (k_swz(r) & (CPR - 1))) << 4);
+  // V transposed read (A operand of PV): 16-lane group g2 = (lane>>4)&1 covers dv
+  // columns 16*g2..16*g2+15 of a 32-wide dv block; lane (4*qq+pp) of the group
+  // addresses row (key) r0+qq, columns 4pp..4pp+3.  r0 = 16*st + 4*hh (+8 for the
+  // second read) so that element j of this lane is key 16st + 8(j>>2) + 4hh + (j&3),
+  // the order in which the S^T accumulator registers hold P.
+  const int li = lane & 15, qq = li >> 2, pp = li & 3, g2 = (lane >> 4) & 1;
+  // byte offset inside a V tile for (key row, dv block dvb) computed at use.
+
+  f32x16 oacc[DVB];
+#pragma unroll
+  for (int d = 0; d < DVB; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  float m_run = -INFINITY;  // running max of RAW scores (scale applied in the exponent)
+  float l_run = 0.f;        // this lane's partial row sum (its 32 of every 64 keys)
+  const float c = p.scale_log2;
+
+  const int ntiles = (p.Sk + KV - 1) / KV;
+  stage(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const int k0 = t * KV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) stage(cur ^ 1, k0 + KV);
+    const unsigned char* kt = smem + cur * STAGE_BYTES;
+    const unsigned char* vt = kt + TILE_BYTES;
+
+    // ---- S^T = K Q^T : two 32-key blocks ------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + kb * 32 * ROWB + koff[s]);
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+    // mask keys past the end (last tile only; wave-uniform branch)
+    if (k0 + KV > p.Sk) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (key >= p.Sk) sacc[kb][e] = -INFINITY;
+        }
+    }
+    // ---- online softmax (query on the lane) -----------------------------------
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    m_run = m_new;
+    float rs = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pe[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        pe[e] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], c, -mc));
+        rs += pe[e];
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[kb][st][j] = (__bf16)pe[8 * st + j];
+    }
+    l_run = l_run * alpha + rs;
+#pragma unroll
+    for (int d = 0; d < DVB; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+
+    // ---- O^T += V^T P^T ---------------------------------------------------------
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int d = 0; d < DVB; ++d) {
+          bf16x8 vf;
+          if constexpr (TRREAD) {
+            bf16x4 tv[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const int key = kb * 32 + st * 16 + half * 8 + 4 * hh + qq;  // row this lane addresses
+              const int col = d * 32 + g2 * 16 + 4 * pp;                    // first of 4 columns
+              const int ch = col >> 3;
+              const int off =
+                  key * ROWB + (((ch ^ (v_swz(key) & (CPR - 1)))) << 4) + ((col & 7) << 1);
+              tv[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                  (__attribute__((address_space(3))) bf16x4*)(vt + off));
+            }
+            vf = __builtin_shufflevector(tv[0], tv[1], 0, 1, 2, 3, 4, 5, 6, 7);
+          } else {
+            // debug path: element gathers, same image
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+              const int key = kb * 32 + st * 16 + (jj >> 2) * 8 + 4 * hh + (jj & 3);
+              const int col = d * 32 + r;
+              const int off = key * ROWB + ((((col >> 3) ^ (v_swz(key) & (CPR - 1)))) << 4) +
+                              ((col & 7) << 1);
+              vf[jj] = __builtin_bit_cast(__bf16, *reinterpret_cast<const unsigned short*>(vt + off));
+            }
+          }
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][st], oacc[d], 0, 0, 0);
+        }
+  }
+
+  // ---- finish: combine the two half-row sums, normalise, store -------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  const int qrow = q0 + r;
+  const bool q_ok = qrow < p.Sq;
+  if (p.lse && q_ok && hh == 0) {
+    // natural-log LSE of the scaled scores
+    p.lse[((int64_t)b * p.H + head) * p.Sq + qrow] =
+        (m_run * c + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+  unsigned short* op = p.o + b * p.o_sb + (int64_t)(q_ok ? qrow : 0) * p.o_ss + head * p.o_sh;
+#pragma unroll
+  for (int d = 0; d < DVB; ++d) {
+    unsigned int pk[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      pk[g][0] = pack_bf2(oacc[d][4 * g] * inv_l, oacc[d][4 * g + 1] * inv_l);
+      pk[g][1] = pack_bf2(oacc[d][4 * g + 2] * inv_l, oacc[d][4 * g + 3] * inv_l);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2) {
+        auto sw = __builtin_amdgcn_permlane32_swap(pk[g][w2], pk[g + 1][w2], false, false);
+        pk[g][w2] = sw[0];
+        pk[g + 1][w2] = sw[1];
+      }
+      if (q_ok) {
+        const int dv8 = d * 32 + 8 * (g + hh);
+        *reinterpret_cast<u32x4*>(op + dv8) = u32x4{pk[g][0], pk[g][1], pk[g + 1][0], pk[g + 1][1]};
+      }
+    }
+  }
+}
+
+template <int D, bool TRREAD>
+int launch_attn(const AttnParams& p, hipStream_t st) {
+  constexpr int LDS = 2 * 2 * 64 * D * 2;
+  static bool attr_set = false;
+  auto kfn = attn_fwd_kernel<D, TRREAD>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mi355_set_error("flash_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MI355_EHIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((p.Sq + 127) / 128), (unsigned)p.H, (unsigned)p.B), block(256);
+  hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+  MI355_CHECK_LAUNCH("flash_attn_fwd");
+  return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int mi355_flash_attn_fwd(const void* q, const void* k, const void* v, void* out,
+                                    float* lse, int64_t B, int64_t Sq, int64_t Sk, int64_t H,
+                                    int64_t Hk, int64_t D, int64_t q_sb, int64_t q_ss,
+                                    int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+                                    int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
+                                    int64_t o_ss, int64_t o_sh, float softmax_scale, int causal,
+                                    void* stream) {
+  MI355_REQUIRE(q && k && v && out, "flash_attn_fwd: null pointer");
+  if (causal) {
+    mi355_set_error("flash_attn_fwd: causal masking is not built (the DiT path is non-causal)");
+    return MI355_ENOSUP;
+  }
+  MI355_REQUIRE(D == 128 || D == 64, "flash_attn_fwd: head size %ld not in {64,128}", (long)D);
+  MI355_REQUIRE(B >= 0 && Sq >= 0 && Sk >= 0 && H > 0 && Hk > 0 && H % Hk == 0,
+                "flash_attn_fwd: bad shape B=%ld Sq=%ld Sk=%ld H=%ld Hk=%ld", (long)B, (long)Sq,
+                (long)Sk, (long)H, (long)Hk);
+  MI355_REQUIRE(Sq < (1ll << 31) && Sk < (1ll << 31) && H < 65536 && B < 65536,
+                "flash_attn_fwd: dimension too large");
+  const int64_t strides[] = {q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh};
+  for (int64_t s : strides)
+    MI355_REQUIRE(s % 8 == 0, "flash_attn_fwd: strides must be multiples of 8 elements");
+  MI355_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                    ((uintptr_t)out % 16) == 0,
+                "flash_attn_fwd: q/k/v/out must be 16-byte aligned");
+  if (B == 0 || Sq == 0) return MI355_OK;
+  MI355_REQUIRE(Sk > 0, "flash_attn_fwd: empty key sequence");
+  AttnParams p;
+  p.q = (const unsigned short*)q;
+  p.k = (const unsigned short*)k;
+  p.v = (const unsigned short*)v;
+  p.o = (unsigned short*)out;
+  p.lse = lse;
+  p.B = (int)B;
+  p.Sq = (int)Sq;
+  p.Sk = (int)Sk;
+  p.H = (int)H;
+  p.Hk = (int)Hk;
+  p.q_sb = q_sb; p.q_ss = q_ss; p.q_sh = q_sh;
+  p.k_sb = k_sb; p.k_ss = k_ss; p.k_sh = k_sh;
+  p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh;
+  p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
+  p.scale_log2 = softmax_scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  static const bool no_tr = getenv("MI355_ATTN_NO_TR") != nullptr;  // debugging aid
+  if (no_tr) return D == 128 ? launch_attn<128, false>(p, st) : launch_attn<64, false>(p, st);
+  return D == 128 ? launch_attn<128, true>(p, st) : launch_attn<64, true>(p, st);
+}

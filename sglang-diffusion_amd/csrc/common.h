@@ -1,0 +1,117 @@
+// Shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mi355_dit.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define FP8_E4M3_MAX 448.0f
+
+// ---- host-side error plumbing -------------------------------------------
+void mi355_set_error(const char* fmt, ...);
+
+#define MI355_REQUIRE(cond, ...)          \
+  do {                                    \
+    if (!(cond)) {                        \
+      mi355_set_error(__VA_ARGS__);       \
+      return MI355_EINVAL;                \
+    }                                     \
+  } while (0)
+
+#define MI355_CHECK_LAUNCH(name)                                              \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      mi355_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return MI355_EHIP;                                                      \
+    }                                                                         \
+  } while (0)
+
+// ---- bf16 <-> f32 ----------------------------------------------------------
+__device__ __forceinline__ float bf2f(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+// Round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and
+// keeps NaN a NaN.
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+// f32 -> bf16 -> f32 (an eager-mode bf16 rounding point)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+// ---- f32 -> fp8 e4m3fn (OCP on gfx950), round-to-nearest-even ---------------
+// v_cvt_pk_fp8_f32 converts two floats into two bytes of a dword.
+__device__ __forceinline__ unsigned int cvt4_fp8(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned int)w;
+}
+__device__ __forceinline__ float clamp_fp8(float v, float lo, float hi) {
+  return fmaxf(fminf(v, hi), lo);
+}
+
+// ---- wave (64 lanes) reductions ---------------------------------------------
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ int64_t map_row(int64_t m, int64_t rpb, int64_t brows, int64_t off) {
+  if (rpb == 0) return m;
+  int64_t b = m / rpb;
+  return b * brows + off + (m - b * rpb);
+}
+
+// 32-bit form for kernels whose row counts fit an int (cheap unsigned divide)
+__device__ __forceinline__ int64_t map_row32(int m, int rpb, int64_t brows, int64_t off) {
+  if (rpb == 0) return m;
+  const unsigned b = (unsigned)m / (unsigned)rpb;
+  return (int64_t)b * brows + off + (int64_t)((unsigned)m - b * (unsigned)rpb);
+}
+
+// tanh-GELU in fp32: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3))) with
+// tanh(u) = 1 - 2/(exp(2u)+1) on the hardware exp2/rcp units (abs error ~1e-7,
+// far below the bf16 rounding applied to the result).
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float kBeta = 0.7978845608028654f;
+  const float kKappa = 0.044715f;
+  const float inner = kBeta * (x + kKappa * x * x * x);
+  const float t = __builtin_amdgcn_exp2f(inner * 2.8853900817779268f);  // exp(2*inner)
+  const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+  return 0.5f * x * (1.0f + th);
+}
+__device__ __forceinline__ float silu_f(float x) {
+  return x / (1.0f + __expf(-x));
+}
+
+static inline mi355_rowmap rowmap_or_identity(const mi355_rowmap* p) {
+  mi355_rowmap r = {0, 0, 0};
+  if (p) r = *p;
+  return r;
+}

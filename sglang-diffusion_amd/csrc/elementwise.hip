@@ -1,0 +1,727 @@
+// HBM-bound glue kernels of the DiT step for gfx950: norms, RoPE, AdaLN
+// modulation, gated residuals, activations, timestep embedding, Euler/CFG.
+//
+// Common shape: 16-byte accesses per lane, one wavefront (or a 16-lane slice
+// of one) per row with the row held in registers, fp32 math, and every bf16
+// rounding that the eager PyTorch sequence performs reproduced in registers so
+// results match op-by-op execution.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = __uint_as_float(v[j] << 16);
+    f[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float* f) {
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pack_bf2(f[2 * j], f[2 * j + 1]);
+  return o;
+}
+
+// ------------------------------------------------------------------ rmsnorm --
+// One wavefront per row; two sweeps (the second is served from L1/L2).
+template <bool W_F32>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(unsigned short* __restrict__ out,
+                                                      const unsigned short* __restrict__ x,
+                                                      const void* __restrict__ w, int64_t rows,
+                                                      int dim, int64_t ldx, int64_t ldo,
+                                                      float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx);
+  const int nvec = dim >> 3;
+  float ss = 0.f;
+  for (int i = lane; i < nvec; i += 64) {
+    float f[8];
+    unpack8(xr[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+  }
+  ss = group_sum<64>(ss);
+  const float rs = rsqrtf(ss / (float)dim + eps);
+  u32x4* orow = reinterpret_cast<u32x4*>(out + row * ldo);
+  for (int i = lane; i < nvec; i += 64) {
+    float f[8], wv[8];
+    unpack8(xr[i], f);
+    if constexpr (W_F32) {
+      const f32x4 a = reinterpret_cast<const f32x4*>(w)[2 * i];
+      const f32x4 b = reinterpret_cast<const f32x4*>(w)[2 * i + 1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wv[j] = a[j];
+        wv[4 + j] = b[j];
+      }
+    } else {
+      unpack8(reinterpret_cast<const u32x4*>(w)[i], wv);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (f[j] * rs) * wv[j];
+    orow[i] = pack8(f);
+  }
+}
+
+// fused_add_rmsnorm: residual <- bf16(x + residual); x <- rmsnorm of the
+// UNROUNDED fp32 sum.  Both are updated in place, so the row is held in
+// registers between the two phases (rows <= 16K elements).
+template <bool W_F32, int NCH>
+__global__ __launch_bounds__(256) void fused_add_rmsnorm_kernel(unsigned short* x,
+                                                                unsigned short* residual,
+                                                                const void* __restrict__ w,
+                                                                int64_t rows, int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  u32x4* xr = reinterpret_cast<u32x4*>(x + row * (int64_t)dim);
+  u32x4* rr = reinterpret_cast<u32x4*>(residual + row * (int64_t)dim);
+  const int nvec = dim >> 3;
+  float v[NCH][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = c * 64 + lane;
+    if (i < nvec) {
+      float g[8];
+      unpack8(xr[i], v[c]);
+      unpack8(rr[i], g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] += g[j];
+        ss += v[c][j] * v[c][j];
+      }
+      rr[i] = pack8(v[c]);
+    }
+  }
+  ss = group_sum<64>(ss);
+  const float rs = rsqrtf(ss / (float)dim + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = c * 64 + lane;
+    if (i < nvec) {
+      float wv[8];
+      if constexpr (W_F32) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(w)[2 * i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(w)[2 * i + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wv[j] = a[j];
+          wv[4 + j] = b[j];
+        }
+      } else {
+        unpack8(reinterpret_cast<const u32x4*>(w)[i], wv);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[c][j] = (v[c][j] * rs) * wv[j];
+      xr[i] = pack8(v[c]);
+    }
+  }
+}
+
+// -------------------------------------------------------- qk norm + rope ----
+// LPR lanes own one (token, head) row of D = 8*LPR elements.  Rows of q come
+// first, then rows of k.  Norm and rotation are both optional.
+template <int LPR>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(
+    unsigned short* q, unsigned short* k, int64_t B, int64_t S, int64_t H, int64_t sb, int64_t ss,
+    int64_t sh, const float* __restrict__ wq0, const float* __restrict__ wk0,
+    const float* __restrict__ wq1, const float* __restrict__ wk1, int64_t s_split, float eps,
+    const float* __restrict__ cosp, const float* __restrict__ sinp, int interleaved) {
+  constexpr int D = 8 * LPR;
+  constexpr int RPB = 256 / LPR;  // rows per block
+  const int sub = threadIdx.x % LPR;
+  const int64_t rows_one = B * S * H;
+  const int64_t gr = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  const bool live = gr < 2 * rows_one;
+  const int64_t g = live ? gr : 2 * rows_one - 1;
+  const bool is_k = g >= rows_one;
+  const int64_t rrow = is_k ? g - rows_one : g;
+  const int64_t hh = rrow % H;
+  const int64_t tok = rrow / H;
+  const int64_t s = tok % S;
+  const int64_t b = tok / S;
+  unsigned short* base = (is_k ? k : q) + b * sb + s * ss + hh * sh;
+  u32x4* p = reinterpret_cast<u32x4*>(base) + sub;
+  float f[8];
+  unpack8(*p, f);
+  const float* wsel = is_k ? (s < s_split ? wk0 : wk1) : (s < s_split ? wq0 : wq1);
+  if (wsel) {
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sq += f[j] * f[j];
+    sq = group_sum<LPR>(sq);
+    const float rs = rsqrtf(sq / (float)D + eps);
+    const f32x4 wa = reinterpret_cast<const f32x4*>(wsel)[2 * sub];
+    const f32x4 wb = reinterpret_cast<const f32x4*>(wsel)[2 * sub + 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[j] = rbf((f[j] * rs) * wa[j]);          // RMSNorm output is rounded to bf16 ...
+      f[4 + j] = rbf((f[4 + j] * rs) * wb[j]);  // ... before RoPE reads it
+    }
+  }
+  if (cosp) {
+    if (interleaved) {
+      const f32x4 c = reinterpret_cast<const f32x4*>(cosp + s * (D / 2))[sub];
+      const f32x4 sn = reinterpret_cast<const f32x4*>(sinp + s * (D / 2))[sub];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x1 = f[2 * j], x2 = f[2 * j + 1];
+        f[2 * j] = fmaf(-x2, sn[j], __fmul_rn(x1, c[j]));
+        f[2 * j + 1] = fmaf(x1, sn[j], __fmul_rn(x2, c[j]));
+      }
+    } else {
+      // neox: element i pairs with i + D/2, held LPR/2 lanes away
+      const bool lo = sub < LPR / 2;
+      const int cidx = (lo ? sub : sub - LPR / 2) * 8;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cosp + s * (D / 2) + cidx);
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosp + s * (D / 2) + cidx + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sinp + s * (D / 2) + cidx);
+      const f32x4 s1 = *reinterpret_cast<const f32x4*>(sinp + s * (D / 2) + cidx + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float other = __shfl_xor(f[j], LPR / 2, 64);
+        const float c = j < 4 ? c0[j] : c1[j - 4];
+        const float sn = j < 4 ? s0[j] : s1[j - 4];
+        // o1 = x1*cos - x2*sin ; o2 = x2*cos + x1*sin
+        f[j] = lo ? fmaf(-other, sn, __fmul_rn(f[j], c)) : fmaf(other, sn, __fmul_rn(f[j], c));
+      }
+    }
+  }
+  if (live) *p = pack8(f);
+}
+
+// sgl_kernel::rotary_embedding semantics: positions-indexed [max_pos, rot_dim]
+// cache (cos | sin), in place on query and key; one thread per rotary pair.
+template <bool CACHE_F32>
+__global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions, unsigned short* q,
+                                        unsigned short* k, int64_t tokens, int Hq, int Hk,
+                                        int head_size, int rot_dim, int64_t q_stride,
+                                        int64_t k_stride, const void* __restrict__ cache,
+                                        int is_neox) {
+  const int half = rot_dim / 2;
+  const int64_t per_tok = (int64_t)(Hq + Hk) * half;
+  const int64_t total = tokens * per_tok;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = idx / per_tok;
+    const int rem = (int)(idx - t * per_tok);
+    const int head = rem / half;
+    const int i = rem - head * half;
+    const int64_t pos = positions[t];
+    float c, s;
+    if constexpr (CACHE_F32) {
+      const float* cp = reinterpret_cast<const float*>(cache) + pos * rot_dim;
+      c = cp[i];
+      s = cp[half + i];
+    } else {
+      const unsigned short* cp = reinterpret_cast<const unsigned short*>(cache) + pos * rot_dim;
+      c = bf2f(cp[i]);
+      s = bf2f(cp[half + i]);
+    }
+    unsigned short* base = head < Hq ? q + t * q_stride + (int64_t)head * head_size
+                                     : k + t * k_stride + (int64_t)(head - Hq) * head_size;
+    const int i1 = is_neox ? i : 2 * i;
+    const int i2 = is_neox ? i + half : 2 * i + 1;
+    const float x1 = bf2f(base[i1]), x2 = bf2f(base[i2]);
+    base[i1] = f2bf(fmaf(-x2, s, __fmul_rn(x1, c)));
+    base[i2] = f2bf(fmaf(x1, s, __fmul_rn(x2, c)));
+  }
+}
+
+// ------------------------------------------------- layernorm + modulation ----
+// One wavefront per row, row in registers (NCH 16-byte chunks per lane).
+// QUANT: additionally per-token fp8 quantise the bf16 result.
+template <int NCH, bool QUANT>
+__global__ __launch_bounds__(256) void layernorm_modulate_kernel(
+    void* __restrict__ out, float* __restrict__ qscale, const unsigned short* __restrict__ x,
+    const unsigned short* __restrict__ shift, const unsigned short* __restrict__ scale, int64_t rows,
+    int T, int dim, int64_t ldx, int64_t ldo, int64_t ldmod, float eps, mi355_rowmap xm,
+    mi355_rowmap om) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t xrow = map_row32((int)row, (int)xm.rows_per_batch, xm.batch_rows, xm.row_offset);
+  const int64_t b = (unsigned)row / (unsigned)T;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + xrow * ldx);
+  const int nvec = dim >> 3;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = c * 64 + lane;
+    if (i < nvec) {
+      unpack8(xr[i], v[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[c][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+    }
+  }
+  sum = group_sum<64>(sum);
+  const float mean = sum / (float)dim;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = c * 64 + lane;
+    if (i < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[c][j] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  sq = group_sum<64>(sq);
+  const float rstd = rsqrtf(sq / (float)dim + eps);
+  const u32x4* shr = shift ? reinterpret_cast<const u32x4*>(shift + b * ldmod) : nullptr;
+  const u32x4* scr = scale ? reinterpret_cast<const u32x4*>(scale + b * ldmod) : nullptr;
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = c * 64 + lane;
+    if (i < nvec) {
+      float sc[8], sh[8];
+      if (scr) unpack8(scr[i], sc);
+      if (shr) unpack8(shr[i], sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float y = rbf((v[c][j] - mean) * rstd);  // LayerNorm output (bf16)
+        if (scr) y = rbf(y * rbf(1.0f + sc[j]));  // * (1 + scale)
+        if (shr) y = rbf(y + sh[j]);              // + shift
+        v[c][j] = y;
+        amax = fmaxf(amax, fabsf(y));
+      }
+    }
+  }
+  if constexpr (!QUANT) {
+    const int64_t orow = map_row32((int)row, (int)om.rows_per_batch, om.batch_rows, om.row_offset);
+    u32x4* op = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + orow * ldo);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = c * 64 + lane;
+      if (i < nvec) op[i] = pack8(v[c]);
+    }
+  } else {
+    amax = group_max<64>(amax);
+    const float qs = amax / FP8_E4M3_MAX;
+    if (lane == 0) qscale[row] = qs;
+    const float inv = (qs == 0.f) ? 0.f : 1.0f / qs;
+    u32x2* op = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(out) + row * (int64_t)dim);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = c * 64 + lane;
+      if (i < nvec) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          f[j] = clamp_fp8(v[c][j] * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+        u32x2 o;
+        o[0] = cvt4_fp8(f[0], f[1], f[2], f[3]);
+        o[1] = cvt4_fp8(f[4], f[5], f[6], f[7]);
+        op[i] = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------- gated residual ----
+__global__ __launch_bounds__(256) void gate_residual_kernel(
+    unsigned short* out, const unsigned short* residual, const unsigned short* __restrict__ gate,
+    const unsigned short* __restrict__ y, int64_t rows, int T, int dim, int64_t ldy, int64_t ldr,
+    int64_t ldo, int64_t ldg, mi355_rowmap ym, mi355_rowmap rm) {
+  const int nvec = dim >> 3;
+  const int64_t total = rows * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / nvec;
+    const int c = (int)(idx - row * nvec);
+    const int64_t b = (unsigned)row / (unsigned)T;
+    const int64_t yrow = map_row32((int)row, (int)ym.rows_per_batch, ym.batch_rows, ym.row_offset);
+    const int64_t rrow = map_row32((int)row, (int)rm.rows_per_batch, rm.batch_rows, rm.row_offset);
+    float fy[8], fg[8], fr[8];
+    unpack8(reinterpret_cast<const u32x4*>(y + yrow * ldy)[c], fy);
+    unpack8(reinterpret_cast<const u32x4*>(gate + b * ldg)[c], fg);
+    unpack8(reinterpret_cast<const u32x4*>(residual + rrow * ldr)[c], fr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fr[j] = fr[j] + rbf(fg[j] * fy[j]);
+    reinterpret_cast<u32x4*>(out + rrow * ldo)[c] = pack8(fr);
+  }
+}
+
+__global__ __launch_bounds__(256) void activation_kernel(unsigned short* __restrict__ out,
+                                                         const unsigned short* __restrict__ x,
+                                                         int64_t rows, int dim, int64_t ldx,
+                                                         int64_t ldo, int act) {
+  const int nvec = dim >> 3;
+  const int64_t total = rows * nvec;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / nvec;
+    const int c = (int)(idx - row * nvec);
+    float f[8];
+    unpack8(reinterpret_cast<const u32x4*>(x + row * ldx)[c], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = act == 0 ? silu_f(f[j]) : gelu_tanh_f(f[j]);
+    reinterpret_cast<u32x4*>(out + row * ldo)[c] = pack8(f);
+  }
+}
+
+// ------------------------------------------------------ timestep embedding --
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, void* __restrict__ out,
+                                          int B, int dim, int flip, float shift, float scale,
+                                          float max_period, int out_bf16) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * half) return;
+  const int b = idx / half, i = idx - b * half;
+  // exponent = -log(max_period) * arange(half) / (half - shift); emb = exp(exponent)
+  const float exponent = __fdiv_rn(__fmul_rn(-logf(max_period), (float)i), (float)half - shift);
+  const float freq = expf(exponent);
+  const float arg = __fmul_rn(scale, __fmul_rn(t[b], freq));
+  const float sv = sinf(arg), cv = cosf(arg);
+  // [sin | cos], halves swapped when flip_sin_to_cos
+  const int si = flip ? half + i : i;
+  const int ci = flip ? i : half + i;
+  if (out_bf16) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(out) + (int64_t)b * dim;
+    o[si] = f2bf(sv);
+    o[ci] = f2bf(cv);
+    if ((dim & 1) && i == 0) o[dim - 1] = 0;
+  } else {
+    float* o = reinterpret_cast<float*>(out) + (int64_t)b * dim;
+    o[si] = sv;
+    o[ci] = cv;
+    if ((dim & 1) && i == 0) o[dim - 1] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------ euler / cfg ---
+__global__ __launch_bounds__(256) void euler_step_kernel(unsigned short* out,
+                                                         const unsigned short* sample,
+                                                         const unsigned short* __restrict__ v,
+                                                         float dt_bf16, int64_t n) {
+  const int64_t nvec = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float fs[8], fv[8];
+    unpack8(reinterpret_cast<const u32x4*>(sample)[i], fs);
+    unpack8(reinterpret_cast<const u32x4*>(v)[i], fv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fs[j] = fs[j] + rbf(dt_bf16 * fv[j]);
+    reinterpret_cast<u32x4*>(out)[i] = pack8(fs);
+  }
+  for (int64_t i = (nvec << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = f2bf(bf2f(sample[i]) + rbf(dt_bf16 * bf2f(v[i])));
+}
+
+__global__ __launch_bounds__(256) void cfg_combine_kernel(unsigned short* out,
+                                                          const unsigned short* cond,
+                                                          const unsigned short* uncond, float s,
+                                                          int64_t n) {
+  const int64_t nvec = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float fc[8], fu[8];
+    unpack8(reinterpret_cast<const u32x4*>(cond)[i], fc);
+    unpack8(reinterpret_cast<const u32x4*>(uncond)[i], fu);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fu[j] = fu[j] + rbf(s * rbf(fc[j] - fu[j]));
+    reinterpret_cast<u32x4*>(out)[i] = pack8(fu);
+  }
+  for (int64_t i = (nvec << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float c = bf2f(cond[i]), u = bf2f(uncond[i]);
+    out[i] = f2bf(u + rbf(s * rbf(c - u)));
+  }
+}
+
+inline unsigned grid_for(int64_t work_items, int per_block = 256, int64_t cap = 4096) {
+  int64_t nb = (work_items + per_block - 1) / per_block;
+  if (nb < 1) nb = 1;
+  if (nb > cap) nb = cap;
+  return (unsigned)nb;
+}
+
+}  // namespace
+
+extern "C" int mi355_rmsnorm(void* out, const void* x, const void* w, int w_is_f32, int64_t rows,
+                             int64_t dim, int64_t ldx, int64_t ldo, float eps, void* stream) {
+  MI355_REQUIRE(out && x && w, "rmsnorm: null pointer");
+  MI355_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0,
+                "rmsnorm: dim (%ld) and strides must be multiples of 8", (long)dim);
+  MI355_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)w % 16) == 0,
+                "rmsnorm: pointers must be 16-byte aligned");
+  if (rows == 0) return MI355_OK;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (w_is_f32)
+    hipLaunchKernelGGL(rmsnorm_kernel<true>, grid, block, 0, st, (unsigned short*)out,
+                       (const unsigned short*)x, w, rows, (int)dim, ldx, ldo, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_kernel<false>, grid, block, 0, st, (unsigned short*)out,
+                       (const unsigned short*)x, w, rows, (int)dim, ldx, ldo, eps);
+  MI355_CHECK_LAUNCH("rmsnorm");
+  return MI355_OK;
+}
+
+extern "C" int mi355_fused_add_rmsnorm(void* x, void* residual, const void* w, int w_is_f32,
+                                       int64_t rows, int64_t dim, float eps, void* stream) {
+  MI355_REQUIRE(x && residual && w, "fused_add_rmsnorm: null pointer");
+  MI355_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, "fused_add_rmsnorm: dim %% 8 != 0");
+  MI355_REQUIRE(dim <= 16384, "fused_add_rmsnorm: dim (%ld) > 16384 not built", (long)dim);
+  MI355_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
+                    ((uintptr_t)w % 16) == 0,
+                "fused_add_rmsnorm: pointers must be 16-byte aligned");
+  if (rows == 0) return MI355_OK;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (int)((dim / 8 + 63) / 64);
+#define FA(WF, N)                                                                                 \
+  hipLaunchKernelGGL((fused_add_rmsnorm_kernel<WF, N>), grid, block, 0, st, (unsigned short*)x,   \
+                     (unsigned short*)residual, w, rows, (int)dim, eps)
+#define FAN(N)        \
+  do {                \
+    if (w_is_f32)     \
+      FA(true, N);    \
+    else              \
+      FA(false, N);   \
+  } while (0)
+  if (nch <= 1) FAN(1);
+  else if (nch <= 2) FAN(2);
+  else if (nch <= 4) FAN(4);
+  else if (nch <= 8) FAN(8);
+  else if (nch <= 16) FAN(16);
+  else FAN(32);
+#undef FAN
+#undef FA
+  MI355_CHECK_LAUNCH("fused_add_rmsnorm");
+  return MI355_OK;
+}
+
+extern "C" int mi355_qk_norm_rope(void* q, void* k, int64_t B, int64_t S, int64_t H, int64_t D,
+                                  int64_t sb, int64_t ss, int64_t sh, const float* wq0,
+                                  const float* wk0, const float* wq1, const float* wk1,
+                                  int64_t s_split, float eps, const float* cos, const float* sin,
+                                  int interleaved, void* stream) {
+  MI355_REQUIRE(q && k, "qk_norm_rope: null pointer");
+  MI355_REQUIRE(D == 128 || D == 64, "qk_norm_rope: head size %ld not in {64,128}", (long)D);
+  MI355_REQUIRE(B >= 0 && S >= 0 && H > 0, "qk_norm_rope: bad shape");
+  MI355_REQUIRE(sb % 8 == 0 && ss % 8 == 0 && sh % 8 == 0 && ((uintptr_t)q % 16) == 0 &&
+                    ((uintptr_t)k % 16) == 0,
+                "qk_norm_rope: q/k rows must be 16-byte aligned");
+  MI355_REQUIRE((cos == nullptr) == (sin == nullptr), "qk_norm_rope: cos and sin go together");
+  MI355_REQUIRE((wq0 == nullptr) == (wk0 == nullptr) && (wq0 == nullptr) == (wq1 == nullptr) &&
+                    (wq0 == nullptr) == (wk1 == nullptr),
+                "qk_norm_rope: give all four norm weights or none");
+  if (cos)
+    MI355_REQUIRE(((uintptr_t)cos % 16) == 0 && ((uintptr_t)sin % 16) == 0,
+                  "qk_norm_rope: cos/sin must be 16-byte aligned");
+  const int64_t rows = 2 * B * S * H;
+  if (rows == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128) {
+    dim3 grid((unsigned)((rows + 15) / 16)), block(256);
+    hipLaunchKernelGGL(qk_norm_rope_kernel<16>, grid, block, 0, st, (unsigned short*)q,
+                       (unsigned short*)k, B, S, H, sb, ss, sh, wq0, wk0, wq1, wk1, s_split, eps,
+                       cos, sin, interleaved);
+  } else {
+    dim3 grid((unsigned)((rows + 31) / 32)), block(256);
+    hipLaunchKernelGGL(qk_norm_rope_kernel<8>, grid, block, 0, st, (unsigned short*)q,
+                       (unsigned short*)k, B, S, H, sb, ss, sh, wq0, wk0, wq1, wk1, s_split, eps,
+                       cos, sin, interleaved);
+  }
+  MI355_CHECK_LAUNCH("qk_norm_rope");
+  return MI355_OK;
+}
+
+extern "C" int mi355_rotary_embedding(const int64_t* positions, void* q, void* k, int64_t tokens,
+                                      int64_t Hq, int64_t Hk, int64_t head_size, int64_t rot_dim,
+                                      int64_t q_stride, int64_t k_stride,
+                                      const void* cos_sin_cache, int cache_is_f32, int is_neox,
+                                      void* stream) {
+  MI355_REQUIRE(positions && q && cos_sin_cache, "rotary_embedding: null pointer");
+  MI355_REQUIRE(k != nullptr || Hk == 0, "rotary_embedding: key missing but Hk > 0");
+  MI355_REQUIRE(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size,
+                "rotary_embedding: rot_dim %ld invalid for head_size %ld", (long)rot_dim,
+                (long)head_size);
+  if (tokens == 0) return MI355_OK;
+  const int64_t total = tokens * (Hq + Hk) * (rot_dim / 2);
+  dim3 grid(grid_for(total)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (cache_is_f32)
+    hipLaunchKernelGGL(rotary_embedding_kernel<true>, grid, block, 0, st, positions,
+                       (unsigned short*)q, (unsigned short*)k, tokens, (int)Hq, (int)Hk,
+                       (int)head_size, (int)rot_dim, q_stride, k_stride, cos_sin_cache, is_neox);
+  else
+    hipLaunchKernelGGL(rotary_embedding_kernel<false>, grid, block, 0, st, positions,
+                       (unsigned short*)q, (unsigned short*)k, tokens, (int)Hq, (int)Hk,
+                       (int)head_size, (int)rot_dim, q_stride, k_stride, cos_sin_cache, is_neox);
+  MI355_CHECK_LAUNCH("rotary_embedding");
+  return MI355_OK;
+}
+
+static int launch_ln_mod(void* out, float* qscale, const void* x, const void* shift,
+                         const void* scale, int64_t B, int64_t T, int64_t dim, int64_t ldx,
+                         int64_t ldo, int64_t ldmod, float eps, const mi355_rowmap* x_map,
+                         const mi355_rowmap* o_map, bool quant, void* stream) {
+  MI355_REQUIRE(out && x, "layernorm_modulate: null pointer");
+  MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0 && dim <= 16384,
+                "layernorm_modulate: dim (%ld) must be a multiple of 8 and <= 16384", (long)dim);
+  MI355_REQUIRE(B * T < (1ll << 31), "layernorm_modulate: too many rows");
+  MI355_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ldmod % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+                    ((uintptr_t)out % 16) == 0 && ((uintptr_t)shift % 16) == 0 &&
+                    ((uintptr_t)scale % 16) == 0,
+                "layernorm_modulate: rows must be 16-byte aligned");
+  const int64_t rows = B * T;
+  if (rows == 0) return MI355_OK;
+  const mi355_rowmap xm = rowmap_or_identity(x_map), om = rowmap_or_identity(o_map);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (int)((dim / 8 + 63) / 64);
+#define LN(N, Q)                                                                                  \
+  hipLaunchKernelGGL((layernorm_modulate_kernel<N, Q>), grid, block, 0, st, out, qscale,          \
+                     (const unsigned short*)x, (const unsigned short*)shift,                      \
+                     (const unsigned short*)scale, rows, (int)T, (int)dim, ldx, ldo, ldmod, eps,  \
+                     xm, om)
+#define LNQ(N)       \
+  do {               \
+    if (quant)       \
+      LN(N, true);   \
+    else             \
+      LN(N, false);  \
+  } while (0)
+  if (nch <= 1) LNQ(1);
+  else if (nch <= 2) LNQ(2);
+  else if (nch <= 4) LNQ(4);
+  else if (nch <= 6) LNQ(6);
+  else if (nch <= 8) LNQ(8);
+  else if (nch <= 16) LNQ(16);
+  else LNQ(32);
+#undef LNQ
+#undef LN
+  MI355_CHECK_LAUNCH("layernorm_modulate");
+  return MI355_OK;
+}
+
+extern "C" int mi355_layernorm_modulate(void* out, const void* x, const void* shift,
+                                        const void* scale, int64_t B, int64_t T, int64_t dim,
+                                        int64_t ldx, int64_t ldo, int64_t ldmod, float eps,
+                                        const mi355_rowmap* x_map, const mi355_rowmap* o_map,
+                                        void* stream) {
+  return launch_ln_mod(out, nullptr, x, shift, scale, B, T, dim, ldx, ldo, ldmod, eps, x_map,
+                       o_map, false, stream);
+}
+
+extern "C" int mi355_layernorm_modulate_quant(void* q, float* s, const void* x, const void* shift,
+                                              const void* scale, int64_t B, int64_t T, int64_t dim,
+                                              int64_t ldx, int64_t ldmod, float eps,
+                                              const mi355_rowmap* x_map, void* stream) {
+  MI355_REQUIRE(s != nullptr, "layernorm_modulate_quant: null scale output");
+  return launch_ln_mod(q, s, x, shift, scale, B, T, dim, ldx, /*ldo*/ 8, ldmod, eps, x_map,
+                       nullptr, true, stream);
+}
+
+extern "C" int mi355_gate_residual(void* out, const void* residual, const void* gate,
+                                   const void* y, int64_t B, int64_t T, int64_t dim, int64_t ldy,
+                                   int64_t ldr, int64_t ldo, int64_t ldg,
+                                   const mi355_rowmap* y_map, const mi355_rowmap* r_map,
+                                   void* stream) {
+  MI355_REQUIRE(out && residual && gate && y, "gate_residual: null pointer");
+  MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0, "gate_residual: dim %% 8 != 0");
+  MI355_REQUIRE(B * T < (1ll << 31), "gate_residual: too many rows");
+  MI355_REQUIRE(ldy % 8 == 0 && ldr % 8 == 0 && ldo % 8 == 0 && ldg % 8 == 0 &&
+                    ((uintptr_t)out % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
+                    ((uintptr_t)gate % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                "gate_residual: rows must be 16-byte aligned");
+  const int64_t rows = B * T;
+  if (rows == 0) return MI355_OK;
+  const mi355_rowmap ym = rowmap_or_identity(y_map), rm = rowmap_or_identity(r_map);
+  dim3 grid(grid_for(rows * (dim / 8))), block(256);
+  hipLaunchKernelGGL(gate_residual_kernel, grid, block, 0, (hipStream_t)stream,
+                     (unsigned short*)out, (const unsigned short*)residual,
+                     (const unsigned short*)gate, (const unsigned short*)y, rows, (int)T, (int)dim,
+                     ldy, ldr, ldo, ldg, ym, rm);
+  MI355_CHECK_LAUNCH("gate_residual");
+  return MI355_OK;
+}
+
+extern "C" int mi355_activation(void* out, const void* x, int64_t rows, int64_t dim, int64_t ldx,
+                                int64_t ldo, int act, void* stream) {
+  MI355_REQUIRE(out && x, "activation: null pointer");
+  MI355_REQUIRE(act == 0 || act == 1, "activation: unknown act %d", act);
+  MI355_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 &&
+                    ((uintptr_t)out % 16) == 0 && ((uintptr_t)x % 16) == 0,
+                "activation: rows must be 16-byte aligned multiples of 8 elements");
+  if (rows == 0) return MI355_OK;
+  dim3 grid(grid_for(rows * (dim / 8))), block(256);
+  hipLaunchKernelGGL(activation_kernel, grid, block, 0, (hipStream_t)stream, (unsigned short*)out,
+                     (const unsigned short*)x, rows, (int)dim, ldx, ldo, act);
+  MI355_CHECK_LAUNCH("activation");
+  return MI355_OK;
+}
+
+extern "C" int mi355_timestep_embedding(const float* t, void* out, int64_t B, int64_t dim,
+                                        int flip_sin_to_cos, float downscale_freq_shift,
+                                        float scale, float max_period, int out_bf16,
+                                        void* stream) {
+  MI355_REQUIRE(t && out, "timestep_embedding: null pointer");
+  MI355_REQUIRE(B >= 0 && dim >= 2, "timestep_embedding: bad shape");
+  if (B == 0) return MI355_OK;
+  const int64_t total = B * (dim / 2);
+  MI355_REQUIRE(total < (1ll << 31), "timestep_embedding: too large");
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipLaunchKernelGGL(timestep_embedding_kernel, grid, block, 0, (hipStream_t)stream, t, out,
+                     (int)B, (int)dim, flip_sin_to_cos, downscale_freq_shift, scale, max_period,
+                     out_bf16);
+  MI355_CHECK_LAUNCH("timestep_embedding");
+  return MI355_OK;
+}
+
+// bf16 rounding on the host (round-to-nearest-even), used for the Euler dt.
+static float host_round_bf16(float f) {
+  union {
+    float f;
+    uint32_t u;
+  } v;
+  v.f = f;
+  if ((v.u & 0x7f800000u) == 0x7f800000u) return f;
+  v.u = (v.u + 0x7fffu + ((v.u >> 16) & 1u)) & 0xffff0000u;
+  return v.f;
+}
+
+extern "C" int mi355_euler_step(void* out, const void* sample, const void* v, float sigma,
+                                float sigma_next, int64_t n, void* stream) {
+  MI355_REQUIRE(out && sample && v, "euler_step: null pointer");
+  MI355_REQUIRE(n >= 0, "euler_step: negative size");
+  MI355_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)sample % 16) == 0 &&
+                    ((uintptr_t)v % 16) == 0,
+                "euler_step: pointers must be 16-byte aligned");
+  if (n == 0) return MI355_OK;
+  const float dt = host_round_bf16(sigma_next - sigma);
+  dim3 grid(grid_for(n / 8 + 1)), block(256);
+  hipLaunchKernelGGL(euler_step_kernel, grid, block, 0, (hipStream_t)stream, (unsigned short*)out,
+                     (const unsigned short*)sample, (const unsigned short*)v, dt, n);
+  MI355_CHECK_LAUNCH("euler_step");
+  return MI355_OK;
+}
+
+extern "C" int mi355_cfg_combine(void* out, const void* cond, const void* uncond, float scale,
+                                 int64_t n, void* stream) {
+  MI355_REQUIRE(out && cond && uncond, "cfg_combine: null pointer");
+  MI355_REQUIRE(n >= 0, "cfg_combine: negative size");
+  MI355_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)cond % 16) == 0 &&
+                    ((uintptr_t)uncond % 16) == 0,
+                "cfg_combine: pointers must be 16-byte aligned");
+  if (n == 0) return MI355_OK;
+  dim3 grid(grid_for(n / 8 + 1)), block(256);
+  hipLaunchKernelGGL(cfg_combine_kernel, grid, block, 0, (hipStream_t)stream, (unsigned short*)out,
+                     (const unsigned short*)cond, (const unsigned short*)uncond, scale, n);
+  MI355_CHECK_LAUNCH("cfg_combine");
+  return MI355_OK;
+}

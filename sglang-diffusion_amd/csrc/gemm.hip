@@ -1,0 +1,557 @@
+// MFMA GEMMs for gfx950:  out[M,N] = epilogue( X[M,K] . W[N,K]^T ).
+//
+// One kernel template serves the bf16 linear (v_mfma_f32_32x32x16_bf16) and
+// the W8A8 fp8 linear (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block
+// scales: the only fp8 MFMA form that runs at twice the bf16 rate on CDNA4;
+// per-token x per-channel scales are applied once, in the epilogue).
+//
+// Data movement.  Both operands are K-contiguous, so an operand tile is
+// [rows][128 bytes] for either dtype (64 bf16 or 128 fp8 along K).  Tiles go
+// HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double
+// buffered, one barrier per K tile.  The LDS image is written lane-linearly
+// (that is what LDS-DMA does), so the bank swizzle is applied to the per-lane
+// SOURCE address and again on the ds_read_b128 side:
+//      physical 16-B chunk = logical chunk ^ ((row >> 1) & 7).
+// With 128-B rows a 256-B bank row holds two tile rows; the XOR spreads the
+// 16 lanes that ds_read_b128 services per cycle over all 16 chunk slots.
+//
+// MFMA orientation.  A-operand = W fragment, B-operand = X fragment, so the
+// 32x32 accumulator has the token (m) on the lane and 4-element runs of n in
+// registers: after one permlane32_swap per register pair every lane owns 8
+// consecutive output channels of one token and stores 16 bytes.
+#include "common.h"
+
+namespace {
+
+struct GemmParams {
+  const unsigned char* a;
+  const unsigned char* w;
+  const float* sa;
+  const float* sb;
+  const unsigned short* bias;
+  unsigned short* out;
+  const unsigned short* residual;
+  const unsigned short* gate;
+  int M, N, ktiles;
+  int64_t lda_b, ldw_b;  // row strides in BYTES
+  int64_t ldo, ldg;      // element strides
+  int64_t gate_rows;
+  mi355_rowmap a_map, o_map;
+  int act;
+  // block-scaled variant
+  int64_t sa_sm, sa_sk, sb_sk, sb_sn;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+
+template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int NPIECE = (BM + BN) / 8 / NW;  // 1-KiB LDS-DMA pieces per wave per K tile
+  static_assert((BM + BN) / 8 % NW == 0, "pieces must divide over waves");
+  constexpr int KSTEPS = DT == 0 ? 4 : 2;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WAVES_M;
+  const int wn = wave / WAVES_M;
+
+  // ---- workgroup -> output tile: XCD-contiguous chunks, 8-row groups ------
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    // blocks b and b+8 share an XCD (and its L2): give each XCD a contiguous
+    // range of tile ids.  Bijective for any nwg.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP = 8;
+  const int group_sz = GROUP * tiles_n;
+  const int gidx = bid / group_sz;
+  const int first_m = gidx * GROUP;
+  const int gm = min(tiles_m - first_m, GROUP);
+  const int in_g = bid - gidx * group_sz;
+  const int tile_m = first_m + in_g % gm;
+  const int tile_n = in_g / gm;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- per-lane LDS-DMA source pointers (advance 128 B per K tile) ---------
+  const unsigned char* src[NPIECE];
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) {
+    const int piece = wave + i * NW;
+    const int row = piece * 8 + (lane >> 3);  // row inside [X tile | W tile]
+    const int pc = lane & 7;
+    const int lc = pc ^ ((row >> 1) & 7);
+    if (piece < BM / 8) {
+      int64_t gmrow = m0 + row;
+      if (gmrow >= p.M) gmrow = p.M - 1;
+      gmrow = map_row32((int)gmrow, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
+                        p.a_map.row_offset);
+      src[i] = p.a + gmrow * p.lda_b + lc * 16;
+    } else {
+      int64_t gnrow = n0 + (row - BM);
+      if (gnrow >= p.N) gnrow = p.N - 1;
+      src[i] = p.w + gnrow * p.ldw_b + lc * 16;
+    }
+  }
+
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int piece = wave + i * NW;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src[i],
+                                       (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16, 0,
+                                       0);
+      src[i] += 128;
+    }
+  };
+
+  // ---- per-lane fragment read offsets --------------------------------------
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int swz = (r >> 1) & 7;
+  int coff[KSTEPS];  // byte offset of the lane's first 16-B chunk for K step s
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    const int c = DT == 0 ? (2 * s + h) : (4 * s + 2 * h);
+    coff[s] = ((c ^ swz) << 4);
+  }
+  const int x_row_off = (wm * TM * 32 + r) * 128;
+  const int w_row_off = BM * 128 + (wn * TN * 32 + r) * 128;
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int unit_scale = 0x7f7f7f7f;  // E8M0 127 = 2^0 in every byte
+
+  // block-scaled variant: scale row pointers
+  const float* sa_row[TM];
+  if constexpr (BLOCKSCALE) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      int64_t m = m0 + wm * TM * 32 + j * 32 + r;
+      if (m >= p.M) m = p.M - 1;
+      sa_row[j] = p.sa + m * p.sa_sm;
+    }
+  }
+
+  stage(0);
+  for (int kt = 0; kt < p.ktiles; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < p.ktiles) stage(cur ^ 1);
+    const unsigned char* sbase = smem + cur * STAGE_BYTES;
+
+    f32x16 part[TN][TM];
+    if constexpr (BLOCKSCALE) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) part[i][j][e] = 0.f;
+    }
+
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      // keep one K step's fragments live at a time (256-VGPR budget at 2 waves/SIMD)
+      if constexpr (DT == 1 && TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DT == 0) {
+        bf16x8 af[TN], bfr[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(sbase + w_row_off + i * 32 * 128 + coff[s]);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8*>(sbase + x_row_off + j * 32 * 128 + coff[s]);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      } else {
+        i32x8 af[TN], bfr[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const unsigned char* pa = sbase + w_row_off + i * 32 * 128;
+          i32x4 lo = *reinterpret_cast<const i32x4*>(pa + coff[s]);
+          i32x4 hi = *reinterpret_cast<const i32x4*>(pa + (coff[s] ^ 16));
+          af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const unsigned char* pb = sbase + x_row_off + j * 32 * 128;
+          i32x4 lo = *reinterpret_cast<const i32x4*>(pb + coff[s]);
+          i32x4 hi = *reinterpret_cast<const i32x4*>(pb + (coff[s] ^ 16));
+          bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            if constexpr (BLOCKSCALE) {
+              part[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                  af[i], bfr[j], part[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                  af[i], bfr[j], acc[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
+            }
+          }
+      }
+    }
+    if constexpr (BLOCKSCALE) {
+      // one K tile == one 128-wide scale block
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        int nb = (n0 + wn * TN * 32 + i * 32) >> 7;
+        const int nb_max = (p.N - 1) >> 7;
+        if (nb > nb_max) nb = nb_max;
+        const float sbv = p.sb[kt * p.sb_sk + nb * p.sb_sn];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const float f = sa_row[j][kt * p.sa_sk] * sbv;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += part[i][j][e] * f;
+        }
+      }
+    }
+  }
+
+  // ---- epilogue (N % 8 == 0 is a launch precondition) -------------------------
+  int64_t orow[TM];
+  float sam[TM];
+  bool m_ok[TM];
+  int64_t grow[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm * TM * 32 + j * 32 + r;
+    m_ok[j] = m < p.M;
+    const int mc = m_ok[j] ? m : p.M - 1;
+    sam[j] = 1.f;
+    if constexpr (DT == 1 && !BLOCKSCALE) sam[j] = p.sa[mc];
+    orow[j] = map_row32(mc, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset) *
+              p.ldo;
+    grow[j] = p.gate ? (int64_t)((unsigned)mc / (unsigned)p.gate_rows) * p.ldg : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int nbase = n0 + wn * TN * 32 + i * 32;
+    // per-channel scale and bias for this lane's 4 runs of 4 channels
+    f32x4 sbv[4], bsv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = nbase + 8 * g + 4 * h;
+      sbv[g] = f32x4{1.f, 1.f, 1.f, 1.f};
+      bsv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n < p.N) {
+        if constexpr (DT == 1 && !BLOCKSCALE) sbv[g] = *reinterpret_cast<const f32x4*>(p.sb + n);
+        if (p.bias) {
+          const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
+          bsv[g] = f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                         __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      unsigned int pk[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][4 * g + e];
+          if constexpr (DT == 1 && !BLOCKSCALE) v = v * sam[j] * sbv[g][e];
+          v += bsv[g][e];
+          if (p.act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
+          y[e] = v;
+        }
+        pk[g][0] = pack_bf2(y[0], y[1]);
+        pk[g][1] = pack_bf2(y[2], y[3]);
+      }
+      // widen: lanes l and l+32 exchange so each owns 8 consecutive channels
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          auto sw = __builtin_amdgcn_permlane32_swap(pk[g][d], pk[g + 1][d], false, false);
+          pk[g][d] = sw[0];
+          pk[g + 1][d] = sw[1];
+        }
+        const int n8 = nbase + 8 * (g + h);
+        if (m_ok[j] && n8 < p.N) {
+          u32x4 o = u32x4{pk[g][0], pk[g][1], pk[g + 1][0], pk[g + 1][1]};
+          if (p.gate) {
+            const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + grow[j] + n8);
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + orow[j] + n8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y0 = __uint_as_float(o[e] << 16), y1 = __uint_as_float(o[e] & 0xffff0000u);
+              const float g0 = __uint_as_float(gv[e] << 16),
+                          g1 = __uint_as_float(gv[e] & 0xffff0000u);
+              const float r0 = __uint_as_float(rv[e] << 16),
+                          r1 = __uint_as_float(rv[e] & 0xffff0000u);
+              o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
+            }
+          }
+          *reinterpret_cast<u32x4*>(p.out + orow[j] + n8) = o;
+        }
+      }
+    }
+  }
+}
+
+// ---- small-M (<= 16 rows) bf16 linear: pure weight streaming ------------------
+// out[m][n] = act( sum_k x[m][k] w[n][k] + bias[n] ).  One wavefront per output
+// channel pair; lanes split K in 16-byte chunks, fp32 accumulate, shuffle reduce.
+// Weights are read exactly once from HBM; x (a few KB) stays in L1/L2.
+template <int MMAX>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+    const unsigned short* __restrict__ bias, unsigned short* __restrict__ out, int M, int N, int K,
+    int64_t ldx, int64_t ldw, int64_t ldo, int act) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const u32x4* wr = reinterpret_cast<const u32x4*>(w + (int64_t)n * ldw);
+  float acc[MMAX];
+#pragma unroll
+  for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
+  const int nvec = K >> 3;
+  for (int idx = lane; idx < nvec; idx += 64) {
+    const u32x4 wv = wr[idx];
+    float wf[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      wf[2 * j] = __uint_as_float(wv[j] << 16);
+      wf[2 * j + 1] = __uint_as_float(wv[j] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) {
+      if (m < M) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + (int64_t)m * ldx + (int64_t)idx * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[m] = fmaf(__uint_as_float(xv[j] << 16), wf[2 * j], acc[m]);
+          acc[m] = fmaf(__uint_as_float(xv[j] & 0xffff0000u), wf[2 * j + 1], acc[m]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MMAX; ++m) acc[m] = group_sum<64>(acc[m]);
+  if (lane == 0) {
+    const float b = bias ? bf2f(bias[n]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) {
+      if (m < M) {
+        float v = acc[m] + b;
+        if (act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
+        out[(int64_t)m * ldo + n] = f2bf(v);
+      }
+    }
+  }
+}
+
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS>
+int launch_gemm(const GemmParams& p, hipStream_t st) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mi355_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MI355_EHIP;
+    }
+    attr_set = true;
+  }
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid((unsigned)(tiles_m * tiles_n)), block(WAVES_M * WAVES_N * 64);
+  hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+  MI355_CHECK_LAUNCH("gemm");
+  return MI355_OK;
+}
+
+int check_common(const mi355_linear_args* a, const char* who) {
+  MI355_REQUIRE(a->a && a->w && a->out, "%s: null pointer", who);
+  MI355_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "%s: bad shape M=%ld N=%ld K=%ld", who,
+                (long)a->M, (long)a->N, (long)a->K);
+  MI355_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31),
+                "%s: dimension exceeds int32", who);
+  MI355_REQUIRE((a->gate == nullptr) == (a->residual == nullptr),
+                "%s: gate and residual must be given together", who);
+  if (a->gate) MI355_REQUIRE(a->gate_rows > 0, "%s: gate_rows must be positive", who);
+  MI355_REQUIRE(a->act == MI355_ACT_NONE || a->act == MI355_ACT_GELU_TANH, "%s: unknown act %d",
+                who, a->act);
+  return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
+  MI355_REQUIRE(a != nullptr, "linear_ex: null args");
+  int rc = check_common(a, "linear_ex");
+  if (rc) return rc;
+  if (a->M == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int esz = a->fp8 ? 1 : 2;
+  if (!a->fp8 && a->M <= 16 && a->a_map.rows_per_batch == 0 && a->o_map.rows_per_batch == 0 &&
+      !a->gate) {
+    MI355_REQUIRE(a->K % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0,
+                  "linear_bf16: K and strides must be multiples of 8");
+    MI355_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0,
+                  "linear_bf16: operands must be 16-byte aligned");
+    dim3 grid((unsigned)((a->N + 3) / 4)), block(256);
+#define SK(MM)                                                                                     \
+  hipLaunchKernelGGL(skinny_linear_kernel<MM>, grid, block, 0, st, (const unsigned short*)a->a,    \
+                     (const unsigned short*)a->w, (const unsigned short*)a->bias,                  \
+                     (unsigned short*)a->out, (int)a->M, (int)a->N, (int)a->K, a->lda, a->ldw,     \
+                     a->ldo, a->act)
+    if (a->M <= 1) SK(1);
+    else if (a->M <= 2) SK(2);
+    else if (a->M <= 4) SK(4);
+    else if (a->M <= 8) SK(8);
+    else SK(16);
+#undef SK
+    MI355_CHECK_LAUNCH("skinny_linear");
+    return MI355_OK;
+  }
+  const int64_t kbytes = a->K * esz;
+  MI355_REQUIRE(kbytes % 128 == 0, "linear: K (%ld) must be a multiple of %d", (long)a->K,
+                128 / esz);
+  MI355_REQUIRE((a->lda * esz) % 16 == 0 && (a->ldw * esz) % 16 == 0,
+                "linear: operand row strides must be 16-byte multiples");
+  MI355_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0,
+                "linear: operands must be 16-byte aligned");
+  MI355_REQUIRE(a->N % 8 == 0, "linear: N (%ld) must be a multiple of 8", (long)a->N);
+  MI355_REQUIRE(a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0 &&
+                    (!a->gate || (a->ldg % 8 == 0 && ((uintptr_t)a->gate % 16) == 0 &&
+                                  ((uintptr_t)a->residual % 16) == 0)),
+                "linear: output/gate/residual rows must be 16-byte aligned");
+  MI355_REQUIRE(!a->fp8 || ((uintptr_t)a->sb % 16) == 0, "fp8 linear: scales_b must be 16-byte aligned");
+  MI355_REQUIRE(!a->bias || ((uintptr_t)a->bias % 8) == 0, "linear: bias must be 8-byte aligned");
+  if (a->fp8) MI355_REQUIRE(a->sa && a->sb, "fp8 linear: scales missing");
+  GemmParams p;
+  p.a = (const unsigned char*)a->a;
+  p.w = (const unsigned char*)a->w;
+  p.sa = a->sa;
+  p.sb = a->sb;
+  p.bias = (const unsigned short*)a->bias;
+  p.out = (unsigned short*)a->out;
+  p.residual = (const unsigned short*)a->residual;
+  p.gate = (const unsigned short*)a->gate;
+  p.M = (int)a->M;
+  p.N = (int)a->N;
+  p.ktiles = (int)(kbytes / 128);
+  p.lda_b = a->lda * esz;
+  p.ldw_b = a->ldw * esz;
+  p.ldo = a->ldo;
+  p.ldg = a->ldg;
+  p.gate_rows = a->gate_rows > 0 ? a->gate_rows : 1;
+  p.a_map = a->a_map;
+  p.o_map = a->o_map;
+  p.act = a->act;
+  p.sa_sm = p.sa_sk = p.sb_sk = p.sb_sn = 0;
+  // Tile choice: 256x256 (8 waves) when the grid still covers the chip, else 128x128.
+  const int64_t big_tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+  const bool big = big_tiles >= 192;
+  if (a->fp8) {
+    return big ? launch_gemm<1, 4, 2, 2, 4, false>(p, st) : launch_gemm<1, 2, 2, 2, 2, false>(p, st);
+  }
+  return big ? launch_gemm<0, 4, 2, 2, 4, false>(p, st) : launch_gemm<0, 2, 2, 2, 2, false>(p, st);
+}
+
+extern "C" int mi355_fp8_scaled_mm(const void* a, const void* b, const float* sa, const float* sb,
+                                   const void* bias, void* out, int64_t M, int64_t N, int64_t K,
+                                   int64_t lda, int64_t ldb, int64_t ldo, void* stream) {
+  mi355_linear_args g = {};
+  g.a = a;
+  g.w = b;
+  g.sa = sa;
+  g.sb = sb;
+  g.bias = bias;
+  g.out = out;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = lda;
+  g.ldw = ldb;
+  g.ldo = ldo;
+  g.fp8 = 1;
+  return mi355_linear_ex(&g, stream);
+}
+
+extern "C" int mi355_linear_bf16(const void* x, const void* w, const void* bias, void* out,
+                                 int64_t M, int64_t N, int64_t K, int64_t ldx, int64_t ldw,
+                                 int64_t ldo, int act, void* stream) {
+  mi355_linear_args g = {};
+  g.a = x;
+  g.w = w;
+  g.bias = bias;
+  g.out = out;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = ldx;
+  g.ldw = ldw;
+  g.ldo = ldo;
+  g.act = act;
+  return mi355_linear_ex(&g, stream);
+}
+
+extern "C" int mi355_fp8_blockwise_scaled_mm(const void* a, const void* b, const float* sa,
+                                             const float* sb, void* out, int64_t M, int64_t N,
+                                             int64_t K, int64_t lda, int64_t ldb, int64_t ldo,
+                                             int64_t sa_sm, int64_t sa_sk, int64_t sb_sk,
+                                             int64_t sb_sn, void* stream) {
+  MI355_REQUIRE(a && b && sa && sb && out, "fp8_blockwise_scaled_mm: null pointer");
+  MI355_REQUIRE(M >= 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31),
+                "fp8_blockwise_scaled_mm: bad shape");
+  MI355_REQUIRE(K % 128 == 0, "fp8_blockwise_scaled_mm: K (%ld) must be a multiple of 128",
+                (long)K);
+  MI355_REQUIRE(lda % 16 == 0 && ldb % 16 == 0 && ((uintptr_t)a % 16) == 0 &&
+                    ((uintptr_t)b % 16) == 0,
+                "fp8_blockwise_scaled_mm: operands must be 16-byte aligned");
+  MI355_REQUIRE(N % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out % 16) == 0,
+                "fp8_blockwise_scaled_mm: N and output rows must be 16-byte multiples");
+  if (M == 0) return MI355_OK;
+  GemmParams p = {};
+  p.a = (const unsigned char*)a;
+  p.w = (const unsigned char*)b;
+  p.sa = sa;
+  p.sb = sb;
+  p.out = (unsigned short*)out;
+  p.M = (int)M;
+  p.N = (int)N;
+  p.ktiles = (int)(K / 128);
+  p.lda_b = lda;
+  p.ldw_b = ldb;
+  p.ldo = ldo;
+  p.gate_rows = 1;
+  p.sa_sm = sa_sm;
+  p.sa_sk = sa_sk;
+  p.sb_sk = sb_sk;
+  p.sb_sn = sb_sn;
+  return launch_gemm<1, 2, 2, 2, 2, true>(p, (hipStream_t)stream);
+}

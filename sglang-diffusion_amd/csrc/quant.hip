@@ -1,0 +1,302 @@
+// Dynamic fp8 (e4m3fn) activation quantisation for gfx950.
+//
+// All three kernels are HBM-bound streaming kernels: 16-byte loads per lane,
+// a 64-lane (sub-)wave reduction for the absmax, 8-byte fp8 stores.  The row
+// is kept in registers between the absmax pass and the quantise pass so the
+// input is read from HBM exactly once (2 B in + 1 B out per element).
+#include "common.h"
+
+// ------------------------------------------------------------- per token --
+// One wavefront per token row; NCH 16-byte chunks per lane (NCH*512 >= K).
+// Arithmetic follows sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:75-103:
+//   scale = absmax / 448 ; inv = scale == 0 ? 0 : 1/scale ; q = sat(x * inv).
+template <int NCH>
+__global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(
+    const unsigned short* __restrict__ x, int64_t M, int K, int64_t ldx,
+    unsigned char* __restrict__ q, float* __restrict__ s) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx);
+  const int nvec = K >> 3;
+  u32x4 v[NCH];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < nvec) {
+      v[i] = xr[idx];
+    } else {
+      v[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[i][j] << 16)));
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[i][j] & 0xffff0000u)));
+    }
+  }
+  amax = group_max<64>(amax);
+  const float scale = amax / FP8_E4M3_MAX;
+  if (lane == 0) s[row] = scale;
+  const float inv = (scale == 0.f) ? 0.f : 1.0f / scale;
+  u32x2* qr = reinterpret_cast<u32x2*>(q + row * (int64_t)K);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int idx = i * 64 + lane;
+    if (idx < nvec) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[2 * j] = clamp_fp8(__uint_as_float(v[i][j] << 16) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+        f[2 * j + 1] =
+            clamp_fp8(__uint_as_float(v[i][j] & 0xffff0000u) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+      }
+      u32x2 o;
+      o[0] = cvt4_fp8(f[0], f[1], f[2], f[3]);
+      o[1] = cvt4_fp8(f[4], f[5], f[6], f[7]);
+      qr[idx] = o;
+    }
+  }
+}
+
+// Rows longer than 32 chunks per lane (K > 16384): two passes over the row,
+// the second served by L2.
+__global__ __launch_bounds__(256) void per_token_quant_fp8_long_kernel(
+    const unsigned short* __restrict__ x, int64_t M, int K, int64_t ldx,
+    unsigned char* __restrict__ q, float* __restrict__ s) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx);
+  const int nvec = K >> 3;
+  float amax = 0.f;
+  for (int idx = lane; idx < nvec; idx += 64) {
+    u32x4 v = xr[idx];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[j] << 16)));
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[j] & 0xffff0000u)));
+    }
+  }
+  amax = group_max<64>(amax);
+  const float scale = amax / FP8_E4M3_MAX;
+  if (lane == 0) s[row] = scale;
+  const float inv = (scale == 0.f) ? 0.f : 1.0f / scale;
+  u32x2* qr = reinterpret_cast<u32x2*>(q + row * (int64_t)K);
+  for (int idx = lane; idx < nvec; idx += 64) {
+    u32x4 v = xr[idx];
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = clamp_fp8(__uint_as_float(v[j] << 16) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+      f[2 * j + 1] =
+          clamp_fp8(__uint_as_float(v[j] & 0xffff0000u) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+    }
+    u32x2 o;
+    o[0] = cvt4_fp8(f[0], f[1], f[2], f[3]);
+    o[1] = cvt4_fp8(f[4], f[5], f[6], f[7]);
+    qr[idx] = o;
+  }
+}
+
+extern "C" int mi355_per_token_quant_fp8(const void* x, int64_t M, int64_t K, int64_t ldx,
+                                         void* q, float* s, void* stream) {
+  MI355_REQUIRE(x && q && s, "per_token_quant_fp8: null pointer");
+  MI355_REQUIRE(M >= 0 && K > 0, "per_token_quant_fp8: bad shape M=%ld K=%ld", (long)M, (long)K);
+  MI355_REQUIRE(K % 8 == 0 && ldx % 8 == 0,
+                "per_token_quant_fp8: K (%ld) and row stride (%ld) must be multiples of 8",
+                (long)K, (long)ldx);
+  MI355_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0,
+                "per_token_quant_fp8: input must be 16-byte and output 8-byte aligned");
+  MI355_REQUIRE(K < (1ll << 31), "per_token_quant_fp8: K too large");
+  if (M == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((M + 3) / 4)), block(256);
+  const unsigned short* xp = (const unsigned short*)x;
+  unsigned char* qp = (unsigned char*)q;
+  const int nch = (int)((K / 8 + 63) / 64);
+#define LAUNCH(N) \
+  hipLaunchKernelGGL(per_token_quant_fp8_kernel<N>, grid, block, 0, st, xp, M, (int)K, ldx, qp, s)
+  if (nch <= 1) LAUNCH(1);
+  else if (nch <= 2) LAUNCH(2);
+  else if (nch <= 4) LAUNCH(4);
+  else if (nch <= 6) LAUNCH(6);
+  else if (nch <= 8) LAUNCH(8);
+  else if (nch <= 16) LAUNCH(16);
+  else if (nch <= 24) LAUNCH(24);
+  else if (nch <= 32) LAUNCH(32);
+  else
+    hipLaunchKernelGGL(per_token_quant_fp8_long_kernel, grid, block, 0, st, xp, M, (int)K, ldx,
+                       qp, s);
+#undef LAUNCH
+  MI355_CHECK_LAUNCH("per_token_quant_fp8");
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------- per group --
+// 16 lanes own one (token, group) pair of `group_size` elements; a wavefront
+// covers 4 consecutive groups.  Follows
+// sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu:25-114:
+//   absmax = max(eps, |x|...) ; y_s = absmax / fp8_max ; q = clamp(x / y_s).
+template <int NCH>  // 16-byte chunks per lane: group_size = NCH*128
+__global__ __launch_bounds__(256) void per_token_group_quant_fp8_kernel(
+    const unsigned short* __restrict__ x, int64_t M, int K, int64_t ldx,
+    unsigned char* __restrict__ q, float* __restrict__ s, int64_t s_stride_m,
+    int64_t s_stride_g, int group_size, int groups_per_row, float eps, float fp8_min,
+    float fp8_max) {
+  const int sub = threadIdx.x & 15;
+  const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t total = M * groups_per_row;
+  // every lane of a wave must reach the shuffles: clamp instead of returning
+  const bool live = gid < total;
+  const int64_t g = live ? gid : total - 1;
+  const int64_t row = g / groups_per_row;
+  const int grp = (int)(g - row * groups_per_row);
+  const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx + (int64_t)grp * group_size);
+  u32x4 v[NCH];
+  float amax = eps;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    v[i] = xr[i * 16 + sub];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[i][j] << 16)));
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[i][j] & 0xffff0000u)));
+    }
+  }
+  amax = group_max<16>(amax);
+  const float y_s = amax / fp8_max;
+  if (live && sub == 0) s[row * s_stride_m + grp * s_stride_g] = y_s;
+  if (!live) return;
+  u32x2* qr = reinterpret_cast<u32x2*>(q + row * (int64_t)K + (int64_t)grp * group_size);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = clamp_fp8(__uint_as_float(v[i][j] << 16) / y_s, fp8_min, fp8_max);
+      f[2 * j + 1] = clamp_fp8(__uint_as_float(v[i][j] & 0xffff0000u) / y_s, fp8_min, fp8_max);
+    }
+    u32x2 o;
+    o[0] = cvt4_fp8(f[0], f[1], f[2], f[3]);
+    o[1] = cvt4_fp8(f[4], f[5], f[6], f[7]);
+    qr[i * 16 + sub] = o;
+  }
+}
+
+extern "C" int mi355_per_token_group_quant_fp8(const void* x, int64_t M, int64_t K, int64_t ldx,
+                                               void* q, float* s, int64_t s_stride_m,
+                                               int64_t s_stride_g, int group_size, float eps,
+                                               float fp8_min, float fp8_max, int scale_ue8m0,
+                                               void* stream) {
+  MI355_REQUIRE(x && q && s, "per_token_group_quant_fp8: null pointer");
+  if (scale_ue8m0) {
+    mi355_set_error("per_token_group_quant_fp8: packed UE8M0 scales are not built");
+    return MI355_ENOSUP;
+  }
+  MI355_REQUIRE(group_size == 128 || group_size == 256 || group_size == 512,
+                "per_token_group_quant_fp8: group_size %d not in {128,256,512}", group_size);
+  MI355_REQUIRE(K > 0 && K % group_size == 0,
+                "per_token_group_quant_fp8: K (%ld) not a multiple of group_size (%d)", (long)K,
+                group_size);
+  MI355_REQUIRE(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0,
+                "per_token_group_quant_fp8: misaligned input/output");
+  if (M == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int gpr = (int)(K / group_size);
+  const int64_t total = M * gpr;
+  dim3 grid((unsigned)((total + 15) / 16)), block(256);
+  const unsigned short* xp = (const unsigned short*)x;
+  unsigned char* qp = (unsigned char*)q;
+#define LAUNCH(N)                                                                            \
+  hipLaunchKernelGGL(per_token_group_quant_fp8_kernel<N>, grid, block, 0, st, xp, M, (int)K, \
+                     ldx, qp, s, s_stride_m, s_stride_g, group_size, gpr, eps, fp8_min, fp8_max)
+  if (group_size == 128) LAUNCH(1);
+  else if (group_size == 256) LAUNCH(2);
+  else LAUNCH(4);
+#undef LAUNCH
+  MI355_CHECK_LAUNCH("per_token_group_quant_fp8");
+  return MI355_OK;
+}
+
+// ------------------------------------------------------------ per tensor --
+// Two kernels as in sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:10-94: a
+// grid-stride absmax folded into s[0] with an integer atomic max (non-negative
+// floats order like their bit patterns), then q = sat(x * (1/s[0])).
+__global__ __launch_bounds__(256) void per_tensor_absmax_kernel(
+    const unsigned short* __restrict__ x, int64_t n, float* __restrict__ s) {
+  __shared__ float red[4];
+  const int64_t nvec = n >> 3;
+  const u32x4* xv = reinterpret_cast<const u32x4*>(x);
+  float amax = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    u32x4 v = xv[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[j] << 16)));
+      amax = fmaxf(amax, fabsf(__uint_as_float(v[j] & 0xffff0000u)));
+    }
+  }
+  for (int64_t i = (nvec << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    amax = fmaxf(amax, fabsf(bf2f(x[i])));
+  amax = group_max<64>(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(reinterpret_cast<unsigned int*>(s), __float_as_uint(amax / FP8_E4M3_MAX));
+  }
+}
+
+__global__ __launch_bounds__(256) void per_tensor_quant_fp8_kernel(
+    const unsigned short* __restrict__ x, int64_t n, unsigned char* __restrict__ q,
+    const float* __restrict__ s) {
+  const float inv = 1.0f / (*s);
+  const int64_t nvec = n >> 3;
+  const u32x4* xv = reinterpret_cast<const u32x4*>(x);
+  u32x2* qv = reinterpret_cast<u32x2*>(q);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    u32x4 v = xv[i];
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = clamp_fp8(__uint_as_float(v[j] << 16) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+      f[2 * j + 1] =
+          clamp_fp8(__uint_as_float(v[j] & 0xffff0000u) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+    }
+    u32x2 o;
+    o[0] = cvt4_fp8(f[0], f[1], f[2], f[3]);
+    o[1] = cvt4_fp8(f[4], f[5], f[6], f[7]);
+    qv[i] = o;
+  }
+  for (int64_t i = (nvec << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float f = clamp_fp8(bf2f(x[i]) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+    q[i] = (unsigned char)(cvt4_fp8(f, 0.f, 0.f, 0.f) & 0xffu);
+  }
+}
+
+extern "C" int mi355_per_tensor_quant_fp8(const void* x, int64_t numel, void* q, float* s,
+                                          int is_static, void* stream) {
+  MI355_REQUIRE(x && q && s, "per_tensor_quant_fp8: null pointer");
+  MI355_REQUIRE(numel >= 0, "per_tensor_quant_fp8: negative numel");
+  MI355_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0,
+                "per_tensor_quant_fp8: misaligned input/output");
+  if (numel == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t nb = (numel / 8 + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 2048) nb = 2048;
+  dim3 grid((unsigned)nb), block(256);
+  if (!is_static) {
+    hipLaunchKernelGGL(per_tensor_absmax_kernel, grid, block, 0, st, (const unsigned short*)x,
+                       numel, s);
+  }
+  hipLaunchKernelGGL(per_tensor_quant_fp8_kernel, grid, block, 0, st, (const unsigned short*)x,
+                     numel, (unsigned char*)q, (const float*)s);
+  MI355_CHECK_LAUNCH("per_tensor_quant_fp8");
+  return MI355_OK;
+}

@@ -1,0 +1,398 @@
+"""ctypes binding of the C-ABI kernel library (include/mi355_dit.h).
+
+The library is the product; this module only loads it and turns torch tensors
+into (pointer, size, stride, stream) arguments.  There is no fallback: if the
+shared object is missing every op raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355dit.so")
+
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
+_int = ctypes.c_int
+_ptr = ctypes.c_void_p
+
+
+class RowMap(ctypes.Structure):
+    """mi355_rowmap: logical row m -> (m // rows_per_batch) * batch_rows + row_offset + m % rows_per_batch."""
+
+    _fields_ = [("rows_per_batch", _i64), ("batch_rows", _i64), ("row_offset", _i64)]
+
+
+class LinearArgs(ctypes.Structure):
+    _fields_ = [
+        ("a", _ptr),
+        ("w", _ptr),
+        ("sa", _ptr),
+        ("sb", _ptr),
+        ("bias", _ptr),
+        ("out", _ptr),
+        ("residual", _ptr),
+        ("gate", _ptr),
+        ("M", _i64),
+        ("N", _i64),
+        ("K", _i64),
+        ("lda", _i64),
+        ("ldw", _i64),
+        ("ldo", _i64),
+        ("ldg", _i64),
+        ("gate_rows", _i64),
+        ("a_map", RowMap),
+        ("o_map", RowMap),
+        ("fp8", _int),
+        ("act", _int),
+    ]
+
+
+# every symbol include/mi355_dit.h declares, with its argument types
+SIGNATURES = {
+    "mi355_last_error": (ctypes.c_char_p, []),
+    "mi355_abi_version": (_int, []),
+    "mi355_per_token_quant_fp8": (_int, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]),
+    "mi355_per_token_group_quant_fp8": (
+        _int,
+        [_ptr, _i64, _i64, _i64, _ptr, _ptr, _i64, _i64, _int, _f32, _f32, _f32, _int, _ptr],
+    ),
+    "mi355_per_tensor_quant_fp8": (_int, [_ptr, _i64, _ptr, _ptr, _int, _ptr]),
+    "mi355_fp8_scaled_mm": (
+        _int,
+        [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    ),
+    "mi355_fp8_blockwise_scaled_mm": (
+        _int,
+        [_ptr, _ptr, _ptr, _ptr, _ptr] + [_i64] * 10 + [_ptr],
+    ),
+    "mi355_linear_bf16": (_int, [_ptr, _ptr, _ptr, _ptr] + [_i64] * 6 + [_int, _ptr]),
+    "mi355_linear_ex": (_int, [ctypes.POINTER(LinearArgs), _ptr]),
+    "mi355_flash_attn_fwd": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
+    "mi355_rmsnorm": (_int, [_ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _i64, _f32, _ptr]),
+    "mi355_fused_add_rmsnorm": (_int, [_ptr, _ptr, _ptr, _int, _i64, _i64, _f32, _ptr]),
+    "mi355_qk_norm_rope": (
+        _int,
+        [_ptr, _ptr] + [_i64] * 7 + [_ptr] * 4 + [_i64, _f32, _ptr, _ptr, _int, _ptr],
+    ),
+    "mi355_rotary_embedding": (
+        _int,
+        [_ptr, _ptr, _ptr] + [_i64] * 7 + [_ptr, _int, _int, _ptr],
+    ),
+    "mi355_layernorm_modulate": (
+        _int,
+        [_ptr] * 4 + [_i64] * 6 + [_f32, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), _ptr],
+    ),
+    "mi355_layernorm_modulate_quant": (
+        _int,
+        [_ptr] * 5 + [_i64] * 5 + [_f32, ctypes.POINTER(RowMap), _ptr],
+    ),
+    "mi355_gate_residual": (
+        _int,
+        [_ptr] * 4 + [_i64] * 7 + [ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), _ptr],
+    ),
+    "mi355_activation": (_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr]),
+    "mi355_timestep_embedding": (_int, [_ptr, _ptr, _i64, _i64, _int, _f32, _f32, _f32, _int, _ptr]),
+    "mi355_euler_step": (_int, [_ptr, _ptr, _ptr, _f32, _f32, _i64, _ptr]),
+    "mi355_cfg_combine": (_int, [_ptr, _ptr, _ptr, _f32, _i64, _ptr]),
+}
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen the kernel library and attach prototypes; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C sglang-diffusion_amd/csrc` "
+            "(or __graft_entry__.build()); there is no non-HIP fallback"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().mi355_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise RuntimeError("mi355 kernels need tensors on a HIP device (got a CPU tensor)")
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rowmap(m) -> Optional[RowMap]:
+    if m is None:
+        return None
+    return RowMap(int(m[0]), int(m[1]), int(m[2]))
+
+
+# --------------------------------------------------------------------- quant --
+def per_token_quant_fp8(x: torch.Tensor, q: torch.Tensor, s: torch.Tensor) -> None:
+    M, K = x.shape
+    _check(
+        load_library().mi355_per_token_quant_fp8(
+            x.data_ptr(), M, K, x.stride(0), q.data_ptr(), s.data_ptr(), _stream(x)
+        ),
+        "per_token_quant_fp8",
+    )
+
+
+def per_token_group_quant_fp8(x, q, s, group_size, eps, fp8_min, fp8_max, scale_ue8m0) -> None:
+    M, K = x.shape
+    _check(
+        load_library().mi355_per_token_group_quant_fp8(
+            x.data_ptr(), M, K, x.stride(0), q.data_ptr(), s.data_ptr(), s.stride(0), s.stride(1),
+            int(group_size), float(eps), float(fp8_min), float(fp8_max), int(bool(scale_ue8m0)),
+            _stream(x),
+        ),
+        "per_token_group_quant_fp8",
+    )
+
+
+def per_tensor_quant_fp8(x, q, s, is_static: bool) -> None:
+    _check(
+        load_library().mi355_per_tensor_quant_fp8(
+            x.data_ptr(), x.numel(), q.data_ptr(), s.data_ptr(), int(bool(is_static)), _stream(x)
+        ),
+        "per_tensor_quant_fp8",
+    )
+
+
+# ---------------------------------------------------------------------- GEMM --
+def fp8_scaled_mm(a, w, sa, sb, bias, out) -> None:
+    """a [M,K] fp8, w [N,K] fp8 (K contiguous), sa [M], sb [N] fp32, out [M,N] bf16."""
+    M, K = a.shape
+    N = w.shape[0]
+    _check(
+        load_library().mi355_fp8_scaled_mm(
+            a.data_ptr(), w.data_ptr(), sa.data_ptr(), sb.data_ptr(), _p(bias), out.data_ptr(),
+            M, N, K, a.stride(0), w.stride(0), out.stride(0), _stream(a),
+        ),
+        "fp8_scaled_mm",
+    )
+
+
+def fp8_blockwise_scaled_mm(a, w, sa, sb, out, sa_strides, sb_strides) -> None:
+    M, K = a.shape
+    N = w.shape[0]
+    _check(
+        load_library().mi355_fp8_blockwise_scaled_mm(
+            a.data_ptr(), w.data_ptr(), sa.data_ptr(), sb.data_ptr(), out.data_ptr(),
+            M, N, K, a.stride(0), w.stride(0), out.stride(0),
+            sa_strides[0], sa_strides[1], sb_strides[0], sb_strides[1], _stream(a),
+        ),
+        "fp8_blockwise_scaled_mm",
+    )
+
+
+def linear_bf16(x, w, bias, out, act: int = 0) -> None:
+    M, K = x.shape
+    N = w.shape[0]
+    _check(
+        load_library().mi355_linear_bf16(
+            x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), M, N, K,
+            x.stride(0), w.stride(0), out.stride(0), int(act), _stream(x),
+        ),
+        "linear_bf16",
+    )
+
+
+def linear_ex(
+    a, w, out, *, M, N, K, lda, ldw, ldo, sa=None, sb=None, bias=None, residual=None, gate=None,
+    ldg=0, gate_rows=0, a_map=None, o_map=None, fp8=False, act=0,
+) -> None:
+    args = LinearArgs()
+    args.a, args.w, args.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    args.sa, args.sb, args.bias = _p(sa), _p(sb), _p(bias)
+    args.residual, args.gate = _p(residual), _p(gate)
+    args.M, args.N, args.K = M, N, K
+    args.lda, args.ldw, args.ldo, args.ldg = lda, ldw, ldo, ldg
+    args.gate_rows = gate_rows
+    args.a_map = _rowmap(a_map) or RowMap(0, 0, 0)
+    args.o_map = _rowmap(o_map) or RowMap(0, 0, 0)
+    args.fp8 = int(bool(fp8))
+    args.act = int(act)
+    _check(load_library().mi355_linear_ex(ctypes.byref(args), _stream(a)), "linear_ex")
+
+
+# ----------------------------------------------------------------- attention --
+def flash_attn_fwd(q, k, v, out, lse, softmax_scale: float, causal: bool = False) -> None:
+    """q [B,Sq,H,D], k/v [B,Sk,Hk,D], out [B,Sq,H,D] (last dim contiguous)."""
+    B, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    for t in (q, k, v, out):
+        if t.stride(-1) != 1:
+            raise RuntimeError("flash_attn_fwd: last dimension must be contiguous")
+    _check(
+        load_library().mi355_flash_attn_fwd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _p(lse),
+            B, Sq, Sk, H, Hk, D,
+            q.stride(0), q.stride(1), q.stride(2),
+            k.stride(0), k.stride(1), k.stride(2),
+            v.stride(0), v.stride(1), v.stride(2),
+            out.stride(0), out.stride(1), out.stride(2),
+            float(softmax_scale), int(bool(causal)), _stream(q),
+        ),
+        "flash_attn_fwd",
+    )
+
+
+# --------------------------------------------------------------- norm / rope --
+def rmsnorm(out, x, w, eps: float) -> None:
+    rows, dim = x.shape
+    _check(
+        load_library().mi355_rmsnorm(
+            out.data_ptr(), x.data_ptr(), w.data_ptr(), int(w.dtype == torch.float32),
+            rows, dim, x.stride(0), out.stride(0), float(eps), _stream(x),
+        ),
+        "rmsnorm",
+    )
+
+
+def fused_add_rmsnorm(x, residual, w, eps: float) -> None:
+    rows, dim = x.shape
+    _check(
+        load_library().mi355_fused_add_rmsnorm(
+            x.data_ptr(), residual.data_ptr(), w.data_ptr(), int(w.dtype == torch.float32),
+            rows, dim, float(eps), _stream(x),
+        ),
+        "fused_add_rmsnorm",
+    )
+
+
+def qk_norm_rope(q, k, wq0, wk0, wq1, wk1, s_split, eps, cos, sin, interleaved=True) -> None:
+    """In place on q, k [B,S,H,D] (strided views are fine, D contiguous)."""
+    B, S, H, D = q.shape
+    if q.stride() != k.stride() or q.stride(-1) != 1:
+        raise RuntimeError("qk_norm_rope: q and k must share strides, D contiguous")
+    _check(
+        load_library().mi355_qk_norm_rope(
+            q.data_ptr(), k.data_ptr(), B, S, H, D, q.stride(0), q.stride(1), q.stride(2),
+            _p(wq0), _p(wk0), _p(wq1), _p(wk1), int(s_split), float(eps), _p(cos), _p(sin),
+            int(bool(interleaved)), _stream(q),
+        ),
+        "qk_norm_rope",
+    )
+
+
+def rotary_embedding(positions, q, k, head_size, cos_sin_cache, is_neox) -> None:
+    tokens = positions.numel()
+    Hq = q.shape[-1] // head_size if q.dim() == 2 else q.shape[-2]
+    q2 = q.view(tokens, -1)
+    if k is not None:
+        k2 = k.view(tokens, -1)
+        Hk = k2.shape[-1] // head_size
+    else:
+        k2, Hk = None, 0
+    _check(
+        load_library().mi355_rotary_embedding(
+            positions.data_ptr(), q2.data_ptr(), _p(k2), tokens, Hq, Hk, head_size,
+            cos_sin_cache.shape[-1], q2.stride(0), k2.stride(0) if k2 is not None else 0,
+            cos_sin_cache.data_ptr(), int(cos_sin_cache.dtype == torch.float32),
+            int(bool(is_neox)), _stream(q),
+        ),
+        "rotary_embedding",
+    )
+
+
+def layernorm_modulate(out, x, shift, scale, B, T, eps, x_map=None, o_map=None) -> None:
+    dim = x.shape[-1]
+    xm, om = _rowmap(x_map), _rowmap(o_map)
+    mod = shift if shift is not None else scale
+    _check(
+        load_library().mi355_layernorm_modulate(
+            out.data_ptr(), x.data_ptr(), _p(shift), _p(scale), B, T, dim,
+            x.stride(-2), out.stride(-2), mod.stride(0) if mod is not None else 8, float(eps),
+            ctypes.byref(xm) if xm else None, ctypes.byref(om) if om else None, _stream(x),
+        ),
+        "layernorm_modulate",
+    )
+
+
+def layernorm_modulate_quant(q, s, x, shift, scale, B, T, eps, x_map=None) -> None:
+    dim = x.shape[-1]
+    xm = _rowmap(x_map)
+    mod = shift if shift is not None else scale
+    _check(
+        load_library().mi355_layernorm_modulate_quant(
+            q.data_ptr(), s.data_ptr(), x.data_ptr(), _p(shift), _p(scale), B, T, dim,
+            x.stride(-2), mod.stride(0) if mod is not None else 8, float(eps),
+            ctypes.byref(xm) if xm else None, _stream(x),
+        ),
+        "layernorm_modulate_quant",
+    )
+
+
+def gate_residual(out, residual, gate, y, B, T, y_map=None, r_map=None) -> None:
+    dim = y.shape[-1]
+    ym, rm = _rowmap(y_map), _rowmap(r_map)
+    _check(
+        load_library().mi355_gate_residual(
+            out.data_ptr(), residual.data_ptr(), gate.data_ptr(), y.data_ptr(), B, T, dim,
+            y.stride(-2), residual.stride(-2), out.stride(-2), gate.stride(0),
+            ctypes.byref(ym) if ym else None, ctypes.byref(rm) if rm else None, _stream(y),
+        ),
+        "gate_residual",
+    )
+
+
+def activation(out, x, act: int) -> None:
+    rows, dim = x.shape
+    _check(
+        load_library().mi355_activation(
+            out.data_ptr(), x.data_ptr(), rows, dim, x.stride(0), out.stride(0), int(act), _stream(x)
+        ),
+        "activation",
+    )
+
+
+def timestep_embedding(t, out, flip_sin_to_cos, downscale_freq_shift, scale, max_period) -> None:
+    B, dim = out.shape
+    _check(
+        load_library().mi355_timestep_embedding(
+            t.data_ptr(), out.data_ptr(), B, dim, int(bool(flip_sin_to_cos)),
+            float(downscale_freq_shift), float(scale), float(max_period),
+            int(out.dtype == torch.bfloat16), _stream(t),
+        ),
+        "timestep_embedding",
+    )
+
+
+def euler_step(out, sample, v, sigma: float, sigma_next: float) -> None:
+    _check(
+        load_library().mi355_euler_step(
+            out.data_ptr(), sample.data_ptr(), v.data_ptr(), float(sigma), float(sigma_next),
+            sample.numel(), _stream(sample),
+        ),
+        "euler_step",
+    )
+
+
+def cfg_combine(out, cond, uncond, scale: float) -> None:
+    _check(
+        load_library().mi355_cfg_combine(
+            out.data_ptr(), cond.data_ptr(), uncond.data_ptr(), float(scale), cond.numel(),
+            _stream(cond),
+        ),
+        "cfg_combine",
+    )
