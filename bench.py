@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""Benchmark of the Flux.1-dev denoise step on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one denoise step (DiT forward on the fused path + flow-match Euler update) of a
+batch of B = 4 synthetic 1024x1024 requests per GPU, fp8 W8A8 attention/single-block linears,
+bf16 everywhere else: the configuration the metric is quoted on.  With N > 1 every rank owns
+its own batch (data parallel over requests, no collective inside a step): weak scaling, the
+reported value is the whole-job images/s = N*B / (50 * step time).
+
+One JSON line is printed by rank 0.  Besides the contract fields it carries
+  roofline     : the dominant kernel (the 256x256-tile fp8 MFMA GEMM), algorithmic FLOP per
+                 launch / its average duration measured with events on the launch stream,
+                 against the dense fp8 MFMA peak;
+  cpu_baseline : the CPU oracle timed on this host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sglang-diffusion_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA, MI355X
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0
+NUM_INFERENCE_STEPS = 50
+
+
+def flux_step_flops(B: int, S: int = 4608, D: int = 3072, n_double: int = 19, n_single: int = 38,
+                    s_txt: int = 512):
+    """Algorithmic FLOP of one DiT forward: linear 24*D^2*S per block, attention 4*S^2*D."""
+    fp8 = (8 * D * D * S * n_double + 24 * D * D * S * n_single) * B
+    bf16 = 16 * D * D * S * n_double * B
+    attn = 4 * S * S * D * (n_double + n_single) * B
+    return dict(fp8=float(fp8), bf16=float(bf16), attn=float(attn), total=float(fp8 + bf16 + attn))
+
+
+def cpu_baseline(seconds_hint: float = 20.0):
+    """Oracle (CPU restatement of the reference eager path) on a bounded sample: one double +
+    one single block of the FULL-SIZE Flux.1-dev DiT at B = 1, fp8 linears emulated as the
+    reference does on CPU.  Scaled to a whole step by algorithmic FLOP."""
+    from oracle.flux_oracle import FluxOracle
+
+    torch.manual_seed(0)
+    ncores = os.cpu_count() or 1
+    threads = min(ncores, int(os.environ.get("OMP_NUM_THREADS", ncores)))
+    torch.set_num_threads(threads)
+    D, H, dh, S_img, S_txt = 3072, 24, 128, 4096, 512
+    g = torch.Generator().manual_seed(0)
+
+    def w(n, k):
+        return (torch.randn(n, k, generator=g) * k ** -0.5).bfloat16()
+
+    sd = {}
+    def lin(name, n, k):
+        sd[name + ".weight"] = w(n, k)
+        sd[name + ".bias"] = (torch.randn(n, generator=g) * 0.02).bfloat16()
+    p = "transformer_blocks.0"
+    for nm in ("norm1", "norm1_context"):
+        lin(f"{p}.{nm}.linear", 6 * D, D)
+    for nm in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0",
+               "to_add_out"):
+        lin(f"{p}.attn.{nm}", D, D)
+    for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+        sd[f"{p}.attn.{nm}.weight"] = torch.ones(dh)
+    for ff in ("ff", "ff_context"):
+        lin(f"{p}.{ff}.net.0.proj", 4 * D, D)
+        lin(f"{p}.{ff}.net.2", D, 4 * D)
+    q = "single_transformer_blocks.0"
+    lin(f"{q}.norm.linear", 3 * D, D)
+    for nm in ("to_q", "to_k", "to_v"):
+        lin(f"{q}.attn.{nm}", D, D)
+    for nm in ("norm_q", "norm_k"):
+        sd[f"{q}.attn.{nm}.weight"] = torch.ones(dh)
+    lin(f"{q}.proj_mlp", 4 * D, D)
+    lin(f"{q}.proj_out", D, 5 * D)
+    orc = FluxOracle(sd, num_layers=1, num_single_layers=1, num_heads=H, head_dim=dh,
+                     guidance_embeds=True, fp8=True)
+    hid = torch.randn(1, S_img, D, generator=g).bfloat16()
+    enc = torch.randn(1, S_txt, D, generator=g).bfloat16()
+    temb = torch.randn(1, D, generator=g).bfloat16()
+    freqs = orc.freqs_cis(S_txt, 1024, 1024)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        e1, h1 = orc.double_block(0, hid, enc, temb, freqs)
+        orc.single_block(0, h1, e1, temb, freqs)
+    dt = time.perf_counter() - t0
+    S = S_img + S_txt
+    sample_flops = 24 * D * D * S * 2 + 4 * S * S * D * 2
+    full = flux_step_flops(1)["total"]
+    step_s = dt * full / sample_flops
+    return {
+        "value": 1.0 / (NUM_INFERENCE_STEPS * step_s), "unit": "images/s", "cores": threads,
+        "kind": "port",
+        "sample": (f"1 double + 1 single block of the full-size Flux.1-dev DiT, B=1, S=4608, "
+                   f"fp8-emulated linears: {dt:.1f} s for {sample_flops / 1e12:.2f} of "
+                   f"{full / 1e12:.1f} TFLOP per step, scaled by FLOP to {step_s:.0f} s/step"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="requests per GPU")
+    ap.add_argument("--mode", default="fp8", choices=["fp8", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, nargs=2, default=None,
+                    help="(debug) override #double #single blocks; the result is then NOT the metric")
+    args = ap.parse_args()
+
+    from sglang_diffusion_amd.layers.quantization import Fp8Config
+    from sglang_diffusion_amd.models.flux import FluxTransformer2DModel, flux_dev_config
+    from sglang_diffusion_amd.runtime.denoise import DenoisingStage
+    from sglang_diffusion_amd.runtime.parallel import init_distributed
+    from sglang_diffusion_amd.runtime.synthetic import (init_synthetic_weights,
+                                                        make_synthetic_request)
+
+    rank, world, local = init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1
+                                          else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    cfg = flux_dev_config()
+    if args.layers:
+        cfg.num_layers, cfg.num_single_layers = args.layers
+    qc = Fp8Config(is_checkpoint_fp8_serialized=False) if args.mode == "fp8" else None
+    with torch.device(dev):
+        model = FluxTransformer2DModel(cfg, quant_config=qc)
+    init_synthetic_weights(model, seed=0, host_rng=False)
+    model.process_weights_after_loading()
+    stage = DenoisingStage(model, fused=True)
+    B = args.batch
+    req = make_synthetic_request(B, 1024, 1024, NUM_INFERENCE_STEPS, device=dev, seed=rank)
+    timesteps = stage.prepare_timesteps(req, dev)
+    guidance = stage._build_guidance(B, dev, req.embedded_cfg_scale)
+    freqs = stage._freqs_cis(req.prompt_embeds.shape[1], req.width, req.height, dev)
+    ts_host = stage.scheduler._timesteps_host
+    latents = req.latents
+    step_no = [0]
+
+    @torch.no_grad()
+    def one_step():
+        nonlocal latents
+        i = step_no[0] % NUM_INFERENCE_STEPS
+        if i == 0:
+            stage.scheduler._step_index = None
+        t = timesteps[i].repeat(B)
+        noise = stage.predict_noise_with_cfg(req, latents.to(torch.bfloat16), t, guidance, freqs, i)
+        latents = stage.scheduler.step(noise, ts_host[i], latents)[0]
+        step_no[0] += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    step_s = elapsed / args.steps
+    images_per_s = world * B / (NUM_INFERENCE_STEPS * step_s)
+
+    # ---- per-kernel-class timing with events on the launch stream (2 traced steps) -----------
+    eng = model._engine
+    eng.trace = []
+    one_step()
+    one_step()
+    torch.cuda.synchronize()
+    classes = {}
+    for kind, flops, nbytes, e0, e1 in eng.trace:
+        c = classes.setdefault(kind, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, big_ms=0.0,
+                                          big_flops=0.0, big_n=0))
+        ms = e0.elapsed_time(e1)
+        c["ms"] += ms
+        c["flops"] += flops
+        c["bytes"] += nbytes
+        c["n"] += 1
+        # launches large enough for the 256x256-tile kernel (>= 192 tiles: gemm.hip)
+        if kind == "gemm_fp8" and flops >= 2.0 * 16384 * 3072 * 3072:
+            c["big_ms"] += ms
+            c["big_flops"] += flops
+            c["big_n"] += 1
+    eng.trace = None
+    nsteps_traced = 2
+    breakdown = {k: dict(ms_per_step=v["ms"] / nsteps_traced, launches_per_step=v["n"] // nsteps_traced,
+                         tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
+                         gbs=(v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0)
+                 for k, v in classes.items()}
+    g8 = classes.get("gemm_fp8") if args.mode == "fp8" else None
+    if g8 and g8["big_n"]:
+        ach = g8["big_flops"] / (g8["big_ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP8_TFLOPS, "traffic": None,
+                    "kernel": "gemm_kernel<fp8,256x256x128B> (fp8 W8A8 linear)",
+                    "launches_per_step": g8["big_n"] // nsteps_traced,
+                    "avg_launch_us": g8["big_ms"] * 1e3 / g8["big_n"],
+                    "flop_per_launch": g8["big_flops"] / g8["big_n"]}
+    else:
+        gb = classes["gemm_bf16"]
+        ach = gb["flops"] / (gb["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                    "kernel": "gemm_kernel<bf16> (bf16 linear)"}
+    fl = flux_step_flops(B, n_double=cfg.num_layers, n_single=cfg.num_single_layers)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:  # the baseline is informational; never lose the GPU line
+            cpu = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
+                   "sample": f"failed: {type(e).__name__}: {e}"}
+    is_metric_config = args.layers is None and args.mode == "fp8" and B == 4
+    out = {
+        "metric": "images_per_sec_flux1dev_1024x1024_50step_fp8",
+        "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp8_e4m3 (W8A8 attention/single-block linears) + bf16 (FF, attention)",
+        "data": "synthetic",
+        "config": {"workload": ("Flux.1-dev DiT, 1024x1024 (4096 image + 512 text tokens), "
+                                f"{NUM_INFERENCE_STEPS}-step schedule, batch {B} per GPU, "
+                                f"{args.mode}" + ("" if is_metric_config else " [NOT the metric config]")),
+                   "global_batch": world * B, "seq_len": 4608, "parallelism": f"dp{world}",
+                   "num_double_blocks": cfg.num_layers, "num_single_blocks": cfg.num_single_layers},
+        "step_tflops_total": fl["total"] / step_s / 1e12,
+        "mfma_utilisation_vs_fp8_peak": fl["total"] / step_s / 1e12 / PEAK_FP8_TFLOPS,
+        "mixed_roofline_min_ms": (fl["fp8"] / (PEAK_FP8_TFLOPS * 1e12)
+                                  + (fl["bf16"] + fl["attn"]) / (PEAK_BF16_TFLOPS * 1e12)) * 1e3,
+        "roofline": roofline, "breakdown": breakdown, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

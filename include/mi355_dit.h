@@ -127,7 +127,7 @@ typedef struct {
 typedef struct {
   const void* a;        /* activations: fp8 (fp8=1) or bf16 */
   const void* w;        /* weight [N,K]: fp8 or bf16 */
-  const float* sa;      /* [M] per-token scales (fp8 only) */
+  const float* sa;      /* per-token scales (fp8 only), indexed by the MAPPED activation row */
   const float* sb;      /* [N] per-channel scales (fp8 only) */
   const void* bias;     /* bf16 [N] or NULL */
   void* out;            /* bf16 */

@@ -95,16 +95,20 @@ __device__ __forceinline__ int64_t map_row32(int m, int rpb, int64_t brows, int6
   return (int64_t)b * brows + off + (int64_t)((unsigned)m - b * (unsigned)rpb);
 }
 
-// tanh-GELU in fp32: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3))) with
-// tanh(u) = 1 - 2/(exp(2u)+1) on the hardware exp2/rcp units (abs error ~1e-7,
-// far below the bf16 rounding applied to the result).
+// tanh-GELU exactly as eager PyTorch evaluates it in fp32: 0.5*x*(1 + tanh(u)),
+// u = sqrt(2/pi)*(x + 0.044715 x^3), INCLUDING the fp32 rounding of tanh(u) near +-1 (for
+// x << 0 the sum 1 + tanh(u) cancels, and the eager result carries that quantisation, so a
+// more accurate closed form would NOT match it).  tanh(u) = sign(u) * (1 - d),
+// d = 2e/(1+e), e = exp(-2|u|) on the hardware exp2/rcp units; d is accurate to ~1e-7
+// relative, so fl(1 - d) is the correctly rounded tanh up to rare double roundings.
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float kBeta = 0.7978845608028654f;
   const float kKappa = 0.044715f;
-  const float inner = kBeta * (x + kKappa * x * x * x);
-  const float t = __builtin_amdgcn_exp2f(inner * 2.8853900817779268f);  // exp(2*inner)
-  const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
-  return 0.5f * x * (1.0f + th);
+  const float u = kBeta * (x + kKappa * x * x * x);
+  const float e = __builtin_amdgcn_exp2f(fabsf(u) * -2.8853900817779268f);  // exp(-2|u|)
+  const float d = 2.0f * e * __builtin_amdgcn_rcpf(1.0f + e);
+  const float th = copysignf(1.0f - d, u);
+  return (0.5f * x) * (1.0f + th);
 }
 __device__ __forceinline__ float silu_f(float x) {
   return x / (1.0f + __expf(-x));

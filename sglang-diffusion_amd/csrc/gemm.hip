@@ -246,7 +246,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
     m_ok[j] = m < p.M;
     const int mc = m_ok[j] ? m : p.M - 1;
     sam[j] = 1.f;
-    if constexpr (DT == 1 && !BLOCKSCALE) sam[j] = p.sa[mc];
+    // per-token scales live beside the activation rows: index by the mapped A row
+    if constexpr (DT == 1 && !BLOCKSCALE)
+      sam[j] = p.sa[map_row32(mc, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
+                              p.a_map.row_offset)];
     orow[j] = map_row32(mc, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset) *
               p.ldo;
     grow[j] = p.gate ? (int64_t)((unsigned)mc / (unsigned)p.gate_rows) * p.ldg : 0;

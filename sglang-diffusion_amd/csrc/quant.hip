@@ -10,17 +10,21 @@
 // One wavefront per token row; NCH 16-byte chunks per lane (NCH*512 >= K).
 // Arithmetic follows sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:75-103:
 //   scale = absmax / 448 ; inv = scale == 0 ? 0 : 1/scale ; q = sat(x * inv).
-template <int NCH>
+// GROUPSEM: the row is ONE quantisation group with the group-quant arithmetic
+// (absmax floored at eps, q = clamp(x / scale, lo, hi)); used when
+// group_size == K, e.g. per-channel weight quantisation at load time.
+template <int NCH, bool GROUPSEM = false>
 __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(
     const unsigned short* __restrict__ x, int64_t M, int K, int64_t ldx,
-    unsigned char* __restrict__ q, float* __restrict__ s) {
+    unsigned char* __restrict__ q, float* __restrict__ s, float eps = 0.f,
+    float lo = -FP8_E4M3_MAX, float hi = FP8_E4M3_MAX) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * ldx);
   const int nvec = K >> 3;
   u32x4 v[NCH];
-  float amax = 0.f;
+  float amax = GROUPSEM ? eps : 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int idx = i * 64 + lane;
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(
     }
   }
   amax = group_max<64>(amax);
-  const float scale = amax / FP8_E4M3_MAX;
+  const float scale = GROUPSEM ? amax / hi : amax / FP8_E4M3_MAX;
   if (lane == 0) s[row] = scale;
   const float inv = (scale == 0.f) ? 0.f : 1.0f / scale;
   u32x2* qr = reinterpret_cast<u32x2*>(q + row * (int64_t)K);
@@ -47,9 +51,14 @@ __global__ __launch_bounds__(256) void per_token_quant_fp8_kernel(
       float f[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        f[2 * j] = clamp_fp8(__uint_as_float(v[i][j] << 16) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
-        f[2 * j + 1] =
-            clamp_fp8(__uint_as_float(v[i][j] & 0xffff0000u) * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+        const float a = __uint_as_float(v[i][j] << 16), b = __uint_as_float(v[i][j] & 0xffff0000u);
+        if constexpr (GROUPSEM) {
+          f[2 * j] = clamp_fp8(a / scale, lo, hi);
+          f[2 * j + 1] = clamp_fp8(b / scale, lo, hi);
+        } else {
+          f[2 * j] = clamp_fp8(a * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+          f[2 * j + 1] = clamp_fp8(b * inv, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+        }
       }
       u32x2 o;
       o[0] = cvt4_fp8(f[0], f[1], f[2], f[3]);
@@ -101,8 +110,9 @@ __global__ __launch_bounds__(256) void per_token_quant_fp8_long_kernel(
 
 extern "C" int mi355_per_token_quant_fp8(const void* x, int64_t M, int64_t K, int64_t ldx,
                                          void* q, float* s, void* stream) {
-  MI355_REQUIRE(x && q && s, "per_token_quant_fp8: null pointer");
   MI355_REQUIRE(M >= 0 && K > 0, "per_token_quant_fp8: bad shape M=%ld K=%ld", (long)M, (long)K);
+  if (M == 0) return MI355_OK;  // empty batch: nothing to launch (pointers may be null)
+  MI355_REQUIRE(x && q && s, "per_token_quant_fp8: null pointer");
   MI355_REQUIRE(K % 8 == 0 && ldx % 8 == 0,
                 "per_token_quant_fp8: K (%ld) and row stride (%ld) must be multiples of 8",
                 (long)K, (long)ldx);
@@ -116,7 +126,7 @@ extern "C" int mi355_per_token_quant_fp8(const void* x, int64_t M, int64_t K, in
   unsigned char* qp = (unsigned char*)q;
   const int nch = (int)((K / 8 + 63) / 64);
 #define LAUNCH(N) \
-  hipLaunchKernelGGL(per_token_quant_fp8_kernel<N>, grid, block, 0, st, xp, M, (int)K, ldx, qp, s)
+  hipLaunchKernelGGL((per_token_quant_fp8_kernel<N, false>), grid, block, 0, st, xp, M, (int)K, ldx, qp, s, 0.f, -FP8_E4M3_MAX, FP8_E4M3_MAX)
   if (nch <= 1) LAUNCH(1);
   else if (nch <= 2) LAUNCH(2);
   else if (nch <= 4) LAUNCH(4);
@@ -194,8 +204,35 @@ extern "C" int mi355_per_token_group_quant_fp8(const void* x, int64_t M, int64_t
     mi355_set_error("per_token_group_quant_fp8: packed UE8M0 scales are not built");
     return MI355_ENOSUP;
   }
+  if (group_size == K && K % 8 == 0 && K <= 16384 && !(K == 128 || K == 256 || K == 512)) {
+    // one group per row: wave-per-row kernel with the group-quant arithmetic
+    MI355_REQUIRE(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0,
+                  "per_token_group_quant_fp8: misaligned input/output");
+    MI355_REQUIRE(s_stride_m == 1 || M <= 1 || s_stride_g >= 0,
+                  "per_token_group_quant_fp8: bad scale strides");
+    if (M == 0) return MI355_OK;
+    MI355_REQUIRE(s_stride_m == 1, "per_token_group_quant_fp8: group_size == K needs a dense [M,1] scale");
+    hipStream_t st1 = (hipStream_t)stream;
+    dim3 grid1((unsigned)((M + 3) / 4)), block1(256);
+    const unsigned short* xp1 = (const unsigned short*)x;
+    unsigned char* qp1 = (unsigned char*)q;
+    const int nch1 = (int)((K / 8 + 63) / 64);
+#define LAUNCHG(N)                                                                              \
+  hipLaunchKernelGGL((per_token_quant_fp8_kernel<N, true>), grid1, block1, 0, st1, xp1, M, (int)K, \
+                     ldx, qp1, s, eps, fp8_min, fp8_max)
+    if (nch1 <= 1) LAUNCHG(1);
+    else if (nch1 <= 2) LAUNCHG(2);
+    else if (nch1 <= 4) LAUNCHG(4);
+    else if (nch1 <= 8) LAUNCHG(8);
+    else if (nch1 <= 16) LAUNCHG(16);
+    else LAUNCHG(32);
+#undef LAUNCHG
+    MI355_CHECK_LAUNCH("per_token_group_quant_fp8");
+    return MI355_OK;
+  }
   MI355_REQUIRE(group_size == 128 || group_size == 256 || group_size == 512,
-                "per_token_group_quant_fp8: group_size %d not in {128,256,512}", group_size);
+                "per_token_group_quant_fp8: group_size %d not in {128,256,512} nor == K <= 16384",
+                group_size);
   MI355_REQUIRE(K > 0 && K % group_size == 0,
                 "per_token_group_quant_fp8: K (%ld) not a multiple of group_size (%d)", (long)K,
                 group_size);

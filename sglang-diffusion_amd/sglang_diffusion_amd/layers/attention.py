@@ -1,0 +1,274 @@
+"""Attention backend plugin API and the MI355X backend.
+
+Mirrors python/sglang/multimodal_gen/runtime/layers/attention/backends/attention_backend.py:18-170
+(AttentionBackend / AttentionImpl / AttentionMetadata / AttentionMetadataBuilder),
+platforms/interface.py:26-53 (AttentionBackendEnum), selector.py:89-159 (get_attn_backend)
+and layer.py:221-412 (LocalAttention / USPAttention), with ONE backend: the hand-written
+gfx950 flash-attention kernel.  There is no multi-backend dispatch: asking for another
+backend raises.
+"""
+from __future__ import annotations
+
+import enum
+from abc import ABC, abstractmethod
+from dataclasses import dataclass, fields
+from functools import lru_cache
+from typing import Any, Generic, Optional, TypeVar
+
+import torch
+import torch.nn as nn
+
+from .. import _C
+from .forward_context import get_forward_context
+
+
+class AttentionBackendEnum(enum.Enum):
+    """Same members as the reference enum (platforms/interface.py:26-40); only AITER's slot
+    (the ROCm default, server_args.py:1234-1243) is served here, by the MI355X kernel."""
+
+    FA2 = enum.auto()
+    FA = enum.auto()
+    SLIDING_TILE_ATTN = enum.auto()
+    TORCH_SDPA = enum.auto()
+    SAGE_ATTN = enum.auto()
+    SAGE_ATTN_3 = enum.auto()
+    VIDEO_SPARSE_ATTN = enum.auto()
+    SPARSE_VIDEO_GEN_2_ATTN = enum.auto()
+    VMOBA_ATTN = enum.auto()
+    AITER = enum.auto()
+    SLA_ATTN = enum.auto()
+    SAGE_SLA_ATTN = enum.auto()
+    NO_ATTENTION = enum.auto()
+
+    def __str__(self) -> str:
+        return self.name.lower()
+
+
+class AttentionBackend(ABC):
+    accept_output_buffer: bool = False
+
+    @staticmethod
+    @abstractmethod
+    def get_enum() -> AttentionBackendEnum:
+        raise NotImplementedError
+
+    @staticmethod
+    @abstractmethod
+    def get_impl_cls() -> type["AttentionImpl"]:
+        raise NotImplementedError
+
+    @staticmethod
+    @abstractmethod
+    def get_metadata_cls() -> type["AttentionMetadata"]:
+        raise NotImplementedError
+
+    @staticmethod
+    @abstractmethod
+    def get_builder_cls() -> type["AttentionMetadataBuilder"]:
+        return None
+
+
+@dataclass
+class AttentionMetadata:
+    current_timestep: int
+
+    def asdict_zerocopy(self, skip_fields: set[str] | None = None) -> dict[str, Any]:
+        skip_fields = skip_fields or set()
+        return {f.name: getattr(self, f.name) for f in fields(self) if f.name not in skip_fields}
+
+
+T = TypeVar("T", bound=AttentionMetadata)
+
+
+class AttentionMetadataBuilder(ABC, Generic[T]):
+    @abstractmethod
+    def __init__(self) -> None:
+        raise NotImplementedError
+
+    @abstractmethod
+    def prepare(self) -> None:
+        raise NotImplementedError
+
+    @abstractmethod
+    def build(self, **kwargs: dict[str, Any]) -> AttentionMetadata:
+        raise NotImplementedError
+
+
+class AttentionImpl(ABC, Generic[T]):
+    @abstractmethod
+    def __init__(self, num_heads: int, head_size: int, softmax_scale: float, causal: bool = False,
+                 num_kv_heads: int | None = None, prefix: str = "", **extra_impl_args) -> None:
+        raise NotImplementedError
+
+    def preprocess_qkv(self, qkv: torch.Tensor, attn_metadata: T) -> torch.Tensor:
+        return qkv
+
+    def postprocess_output(self, output: torch.Tensor, attn_metadata: T) -> torch.Tensor:
+        return output
+
+    @abstractmethod
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                attn_metadata: T) -> torch.Tensor:
+        raise NotImplementedError
+
+
+# ------------------------------------------------------------ MI355X backend --
+@dataclass
+class Mi355AttentionMetadata(AttentionMetadata):
+    """Dense attention needs no per-step metadata beyond the timestep (the FA backend's
+    cu_seqlens / max_seqlen fields, backends/flash_attn.py, only matter for varlen)."""
+
+
+class Mi355AttentionMetadataBuilder(AttentionMetadataBuilder):
+    def __init__(self) -> None:
+        pass
+
+    def prepare(self) -> None:
+        pass
+
+    def build(self, current_timestep: int = 0, **kwargs) -> Mi355AttentionMetadata:
+        return Mi355AttentionMetadata(current_timestep=current_timestep)
+
+
+class Mi355AttentionImpl(AttentionImpl):
+    """forward(q,k,v,attn_metadata) on [B,S,H,D] bf16, as FlashAttentionImpl / AITerImpl /
+    SDPAImpl (backends/flash_attn.py:436-565, aiter.py:63-93, sdpa.py:55-78)."""
+
+    def __init__(self, num_heads: int, head_size: int, softmax_scale: float, causal: bool = False,
+                 num_kv_heads: int | None = None, prefix: str = "", **extra_impl_args) -> None:
+        if causal:
+            raise NotImplementedError("the MI355X DiT attention kernel is non-causal")
+        if extra_impl_args.get("dropout_p", 0.0):
+            raise ValueError("dropout is not supported (inference only)")
+        if head_size not in (64, 128):
+            raise ValueError(f"head_size {head_size} not supported (64 or 128)")
+        self.num_heads = num_heads
+        self.num_kv_heads = num_kv_heads or num_heads
+        self.head_size = head_size
+        self.softmax_scale = softmax_scale
+        self.causal = causal
+
+    def forward(self, query, key, value, attn_metadata=None, *, return_softmax_lse: bool = False,
+                out: Optional[torch.Tensor] = None):
+        if query.dtype != torch.bfloat16:
+            raise TypeError(f"attention expects bf16, got {query.dtype}")
+        B, S, H, D = query.shape
+        if out is None:
+            out = torch.empty((B, S, H, D), dtype=query.dtype, device=query.device)
+        lse = (torch.empty((B, H, S), dtype=torch.float32, device=query.device)
+               if return_softmax_lse else None)
+        _C.flash_attn_fwd(query, key, value, out, lse, self.softmax_scale, False)
+        return (out, lse) if return_softmax_lse else out
+
+
+class Mi355AttentionBackend(AttentionBackend):
+    accept_output_buffer: bool = True
+
+    @staticmethod
+    def get_supported_head_sizes() -> list[int]:
+        return [64, 128]
+
+    @staticmethod
+    def get_enum() -> AttentionBackendEnum:
+        return AttentionBackendEnum.AITER
+
+    @staticmethod
+    def get_impl_cls() -> type[Mi355AttentionImpl]:
+        return Mi355AttentionImpl
+
+    @staticmethod
+    def get_metadata_cls() -> type[Mi355AttentionMetadata]:
+        return Mi355AttentionMetadata
+
+    @staticmethod
+    def get_builder_cls() -> type[Mi355AttentionMetadataBuilder]:
+        return Mi355AttentionMetadataBuilder
+
+
+def get_attn_backend_cls_str(selected_backend: Optional[AttentionBackendEnum], head_size: int,
+                             dtype: torch.dtype) -> str:
+    """Platform hook, as RocmPlatform.get_attn_backend_cls_str (platforms/rocm.py:95-169)."""
+    if selected_backend not in (None, AttentionBackendEnum.AITER, AttentionBackendEnum.FA):
+        raise ValueError(f"attention backend {selected_backend} is not available on this build; "
+                         "only the MI355X flash-attention kernel is")
+    if dtype != torch.bfloat16:
+        raise ValueError(f"dtype {dtype} not supported by the MI355X attention backend")
+    return f"{__name__}.Mi355AttentionBackend"
+
+
+@lru_cache(maxsize=None)
+def _cached_get_attn_backend(head_size: int, dtype: torch.dtype,
+                             supported: Optional[frozenset]) -> type[AttentionBackend]:
+    if supported is not None and AttentionBackendEnum.AITER not in supported \
+            and AttentionBackendEnum.FA not in supported:
+        raise ValueError(f"none of {sorted(map(str, supported))} is available on this build")
+    get_attn_backend_cls_str(None, head_size, dtype)
+    return Mi355AttentionBackend
+
+
+def get_attn_backend(head_size: int, dtype: torch.dtype,
+                     supported_attention_backends=None) -> type[AttentionBackend]:
+    """selector.py:89-159: cached on (head_size, dtype, supported set)."""
+    sup = frozenset(supported_attention_backends) if supported_attention_backends else None
+    return _cached_get_attn_backend(head_size, dtype, sup)
+
+
+class LocalAttention(nn.Module):
+    """layer.py:221-285."""
+
+    def __init__(self, num_heads: int, head_size: int, num_kv_heads: int | None = None,
+                 softmax_scale: float | None = None, causal: bool = False,
+                 supported_attention_backends=None, **extra_impl_args) -> None:
+        super().__init__()
+        self.softmax_scale = head_size ** -0.5 if softmax_scale is None else softmax_scale
+        num_kv_heads = num_kv_heads or num_heads
+        backend = get_attn_backend(head_size, torch.bfloat16, supported_attention_backends)
+        self.attn_impl = backend.get_impl_cls()(num_heads=num_heads, head_size=head_size,
+                                               softmax_scale=self.softmax_scale,
+                                               num_kv_heads=num_kv_heads, causal=causal,
+                                               **extra_impl_args)
+        self.num_heads, self.head_size, self.num_kv_heads = num_heads, head_size, num_kv_heads
+        self.backend = backend.get_enum()
+
+    def forward(self, q, k, v):
+        assert q.dim() == 4 and k.dim() == 4 and v.dim() == 4, "Expected 4D tensors"
+        return self.attn_impl.forward(q, k, v, attn_metadata=get_forward_context().attn_metadata)
+
+
+class USPAttention(nn.Module):
+    """layer.py:288-412.  With no sequence-parallel group (the data-parallel Flux path) this
+    is local attention; with a Ulysses group it does the head-scatter / sequence-gather
+    all-to-all around the local kernel (layers/usp.py:49-158)."""
+
+    def __init__(self, num_heads: int, head_size: int, num_kv_heads: int | None = None,
+                 softmax_scale: float | None = None, causal: bool = False,
+                 supported_attention_backends=None, prefix: str = "", dropout_rate: float = 0.0,
+                 skip_sequence_parallel: bool = False, ulysses_group=None, **extra_impl_args):
+        super().__init__()
+        self.softmax_scale = head_size ** -0.5 if softmax_scale is None else softmax_scale
+        num_kv_heads = num_kv_heads or num_heads
+        backend = get_attn_backend(head_size, torch.bfloat16, supported_attention_backends)
+        self.attn_impl = backend.get_impl_cls()(num_heads=num_heads, head_size=head_size,
+                                               causal=causal, softmax_scale=self.softmax_scale,
+                                               num_kv_heads=num_kv_heads, prefix=f"{prefix}.impl",
+                                               **extra_impl_args)
+        self.num_heads, self.head_size, self.num_kv_heads = num_heads, head_size, num_kv_heads
+        self.backend = backend.get_enum()
+        self.causal = causal
+        self.skip_sequence_parallel = skip_sequence_parallel
+        self.ulysses_group = ulysses_group
+
+    def forward(self, q, k, v, num_replicated_prefix: int = 0):
+        md = get_forward_context().attn_metadata
+        group = self.ulysses_group
+        if self.skip_sequence_parallel or group is None or group.size() == 1:
+            return self.attn_impl.forward(q, k, v, md)
+        if num_replicated_prefix:
+            raise NotImplementedError("replicated-prefix Ulysses (Flux-2) is not built")
+        from ..runtime.parallel import ulysses_all_to_all
+
+        q = ulysses_all_to_all(q, group, scatter_dim=2, gather_dim=1)
+        k = ulysses_all_to_all(k, group, scatter_dim=2, gather_dim=1)
+        v = ulysses_all_to_all(v, group, scatter_dim=2, gather_dim=1)
+        out = self.attn_impl.forward(q, k, v, md)
+        return ulysses_all_to_all(out, group, scatter_dim=1, gather_dim=2)

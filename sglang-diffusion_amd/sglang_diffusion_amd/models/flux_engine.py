@@ -1,0 +1,290 @@
+"""Fused execution of one Flux DiT forward on MI355X.
+
+Computes exactly what FluxTransformer2DModel.forward computes (reference:
+python/sglang/multimodal_gen/runtime/models/dits/flux.py:838-916 and the block forwards at
+:499-559,620-692), with the eager sequence's bf16 rounding points preserved, but laid out for
+the hardware:
+
+  * HBM layout.  The text and image streams live in ONE joint activation buffer
+    [B, S_txt + S_img, D] from the first block on, so the `torch.cat` / split pairs of the
+    reference (flux.py:380-382,401-408,508,555-558) never move data: GEMMs read and write
+    their stream's rows through a row map.
+  * q, k, v come out of one fused projection GEMM per stream ([3D, D] weight, per-channel
+    scales concatenated) straight into a joint [B, S, 3, H, d] buffer; RMSNorm + RoPE run
+    in place on its q/k slices; the attention kernel reads the strided views.
+  * LayerNorm + AdaLN modulation + dynamic per-token fp8 quantisation is one pass over the
+    hidden state; `gate * y + residual` is the epilogue of the GEMM that produces y.
+  * All 19*2 + 38 + 1 AdaLN modulation linears are one weight-streaming GEMM per step.
+
+Per-token fp8 scales, fp8 activations and all intermediates are caller-invisible workspace
+tensors allocated once per (batch, sequence) shape.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import _C
+from ..layers.quantization import FP8_DTYPE, Fp8LinearMethod, UnquantizedLinearMethod
+
+
+def _is_fp8(lin) -> bool:
+    qm = lin.quant_method
+    if isinstance(qm, Fp8LinearMethod):
+        if qm.block_quant:
+            raise NotImplementedError("block-quantised checkpoints run through `forward` "
+                                      "(module path); the fused engine is per-channel only")
+        if lin.weight.dtype != FP8_DTYPE:
+            raise RuntimeError("call process_weights_after_loading() before the fused path")
+        return True
+    assert isinstance(qm, UnquantizedLinearMethod)
+    return False
+
+
+class _Packed:
+    """Several linears concatenated along N; the modules' parameters become views."""
+
+    def __init__(self, lins: List):
+        self.fp8 = _is_fp8(lins[0])
+        assert all(_is_fp8(l) == self.fp8 for l in lins)
+        self.w = torch.cat([l.weight.data for l in lins], dim=0).contiguous()
+        self.b = (torch.cat([l.bias.data for l in lins], dim=0).contiguous()
+                  if lins[0].bias is not None else None)
+        self.s = (torch.cat([l.weight_scale.data.reshape(-1) for l in lins]).contiguous()
+                  if self.fp8 else None)
+        o = 0
+        for l in lins:  # re-point the module parameters at the packed storage (no 2nd copy)
+            n = l.weight.shape[0]
+            l.weight.data = self.w[o:o + n]
+            if self.b is not None:
+                l.bias.data = self.b[o:o + n]
+            if self.fp8:
+                l.weight_scale.data = self.s[o:o + n]
+            o += n
+        self.N, self.K = self.w.shape
+
+
+class FluxEngine:
+    def __init__(self, model):
+        self.model = model
+        c = model.config
+        self.D = model.inner_dim
+        self.H = c.num_attention_heads
+        self.dh = c.attention_head_dim
+        self.guidance_embeds = c.guidance_embeds
+        D = self.D
+        # ---- one modulation matrix for the whole network ---------------------------
+        mods, self.mod_off = [], {}
+        off = 0
+        for i, blk in enumerate(model.transformer_blocks):
+            for name, m in (("img", blk.norm1), ("txt", blk.norm1_context)):
+                mods.append(m.linear)
+                self.mod_off[("d", i, name)] = off
+                off += 6 * D
+        for i, blk in enumerate(model.single_transformer_blocks):
+            mods.append(blk.norm.linear)
+            self.mod_off[("s", i)] = off
+            off += 3 * D
+        mods.append(model.norm_out.linear)
+        self.mod_off[("out",)] = off
+        off += 2 * D
+        self.n_mod = off
+        self.mod_w = torch.cat([m.weight.data for m in mods], dim=0).contiguous()
+        self.mod_b = torch.cat([m.bias.data for m in mods], dim=0).contiguous()
+        o = 0
+        for m in mods:
+            n = m.weight.shape[0]
+            m.weight.data = self.mod_w[o:o + n]
+            m.bias.data = self.mod_b[o:o + n]
+            o += n
+        # ---- per-block packed projections ---------------------------------------------
+        self.dbl = []
+        for blk in model.transformer_blocks:
+            a = blk.attn
+            self.dbl.append(dict(
+                qkv=_Packed([a.to_q, a.to_k, a.to_v]),
+                add_qkv=_Packed([a.add_q_proj, a.add_k_proj, a.add_v_proj]),
+                to_out=_Packed([a.to_out[0]]), to_add_out=_Packed([a.to_add_out]),
+                ff1=blk.ff.net[0].proj, ff2=blk.ff.net[2],
+                cff1=blk.ff_context.net[0].proj, cff2=blk.ff_context.net[2],
+                nq=a.norm_q.weight.data, nk=a.norm_k.weight.data,
+                naq=a.norm_added_q.weight.data, nak=a.norm_added_k.weight.data,
+                eps=a.norm_q.variance_epsilon))
+        self.sgl = []
+        for blk in model.single_transformer_blocks:
+            a = blk.attn
+            self.sgl.append(dict(
+                qkv=_Packed([a.to_q, a.to_k, a.to_v]), mlp=_Packed([blk.proj_mlp]),
+                out=_Packed([blk.proj_out]), nq=a.norm_q.weight.data, nk=a.norm_k.weight.data,
+                eps=a.norm_q.variance_epsilon))
+        self._ws: Dict[Tuple, dict] = {}
+        # optional per-launch timing: list of (kind, flops, bytes, start_event, end_event)
+        self.trace: Optional[list] = None
+
+    def _run(self, kind: str, flops: float, nbytes: float, fn, *args, **kw):
+        """Launch `fn`; when tracing, bracket it with events on the launch stream."""
+        if self.trace is None:
+            return fn(*args, **kw)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*args, **kw)
+        e1.record()
+        self.trace.append((kind, flops, nbytes, e0, e1))
+
+    # ------------------------------------------------------------------ workspace --
+    def _workspace(self, B: int, Ti: int, Tt: int, dev) -> dict:
+        key = (B, Ti, Tt, str(dev))
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        D, S = self.D, Ti + Tt
+        Mi, Mt, Ms = B * Ti, B * Tt, B * S
+        bf, f8, f32 = torch.bfloat16, FP8_DTYPE, torch.float32
+        mlp = self.model.single_transformer_blocks[0].mlp_hidden_dim \
+            if len(self.model.single_transformer_blocks) else 4 * D
+        e = lambda *shape, dtype=bf: torch.empty(shape, dtype=dtype, device=dev)  # noqa: E731
+        ws = dict(
+            joint=e(Ms, D), mod=e(B, self.n_mod), silu_temb=e(B, D),
+            xq=e(Ms, D, dtype=f8), xs=e(Ms, dtype=f32), xn=e(Ms, D),
+            qkv=e(Ms, 3 * D), attn=e(Ms, D), aq=e(Ms, D, dtype=f8), as_=e(Ms, dtype=f32),
+            ffh=e(max(Mi, Mt), 4 * D), cat=e(Ms, D + mlp), cq=e(Ms, D + mlp, dtype=f8),
+            cs=e(Ms, dtype=f32), out=e(Mi, self.model.proj_out.weight.shape[0]),
+        )
+        self._ws[key] = ws
+        return ws
+
+    # ---------------------------------------------------------------------- helpers --
+    def _lin(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
+             gate=None, gate_rows=0, act=0, ldo=None, lda=None):
+        self._run("gemm_fp8" if pk.fp8 else "gemm_bf16", 2.0 * M * pk.N * pk.K,
+                  (M * pk.K + pk.N * pk.K) * (1 if pk.fp8 else 2) + 2.0 * M * pk.N,
+                  _C.linear_ex, a, pk.w, out, M=M, N=pk.N, K=pk.K, lda=lda or a.stride(0),
+                  ldw=pk.w.stride(0), ldo=ldo or out.stride(0), sa=sa, sb=pk.s, bias=pk.b,
+                  residual=residual, gate=gate, ldg=gate.stride(0) if gate is not None else 0,
+                  gate_rows=gate_rows, a_map=a_map, o_map=o_map, fp8=pk.fp8, act=act)
+
+    def _lin_mod(self, mod, a, out, *, M, o_map=None, residual=None, gate=None, gate_rows=0, act=0):
+        """Unquantised nn.Linear-style module (FF, embedders)."""
+        w = mod.weight.data
+        N, K = w.shape
+        self._run("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), _C.linear_ex, a, w,
+                  out, M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldo=out.stride(0),
+                  bias=mod.bias.data if mod.bias is not None else None, residual=residual,
+                  gate=gate, ldg=gate.stride(0) if gate is not None else 0, gate_rows=gate_rows,
+                  o_map=o_map, fp8=False, act=act)
+
+    # --------------------------------------------------------------------------- step --
+    def step(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance,
+             freqs_cis) -> torch.Tensor:
+        m = self.model
+        D, H, dh = self.D, self.H, self.dh
+        B, Ti, Cin = hidden_states.shape
+        Tt = encoder_hidden_states.shape[1]
+        S = Ti + Tt
+        Mi, Mt, Ms = B * Ti, B * Tt, B * S
+        dev = hidden_states.device
+        ws = self._workspace(B, Ti, Tt, dev)
+        joint, mod = ws["joint"], ws["mod"]
+        map_i, map_t = (Ti, S, Tt), (Tt, S, 0)
+        cos, sin = freqs_cis
+        cos = cos.to(torch.float32).contiguous()
+        sin = sin.to(torch.float32).contiguous()
+
+        # ---- conditioning: temb, then every AdaLN modulation in one GEMM ------------------
+        if self.guidance_embeds and guidance is not None:
+            temb = m.time_text_embed(timestep, guidance, pooled_projections)
+        else:
+            temb = m.time_text_embed(timestep, pooled_projections)
+        _C.activation(ws["silu_temb"], temb.contiguous(), 0)
+        self._run("modulation", 2.0 * B * self.n_mod * D, 2.0 * self.n_mod * D, _C.linear_bf16,
+                  ws["silu_temb"], self.mod_w, self.mod_b, mod, 0)
+
+        def chunk(off, j):
+            return mod[:, off + j * D: off + (j + 1) * D]
+
+        # ---- embedders write their stream's rows of the joint buffer ----------------------
+        self._lin_mod(m.x_embedder, hidden_states.reshape(Mi, Cin), joint, M=Mi, o_map=map_i)
+        self._lin_mod(m.context_embedder,
+                      encoder_hidden_states.reshape(Mt, encoder_hidden_states.shape[-1]), joint,
+                      M=Mt, o_map=map_t)
+
+        qkv = ws["qkv"]
+        qkv5 = qkv.view(B, S, 3, H, dh)
+        q, k, v = qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2]
+        attn = ws["attn"]
+        attn4 = attn.view(B, S, H, dh)
+        scale = dh ** -0.5
+
+        def norm_in(pk_fp8, shift, scl, T, rmap, M):
+            """LayerNorm + modulation (+ fp8 quant) of one stream -> (activation, scales)."""
+            if pk_fp8:
+                self._run("elementwise", 0.0, 3.0 * M * D, _C.layernorm_modulate_quant, ws["xq"],
+                          ws["xs"], joint, shift, scl, B, T, 1e-6, x_map=rmap)
+                return ws["xq"], ws["xs"]
+            self._run("elementwise", 0.0, 4.0 * M * D, _C.layernorm_modulate, ws["xn"], joint,
+                      shift, scl, B, T, 1e-6, x_map=rmap)
+            return ws["xn"], None
+
+        # ------------------------------------------------------------------ double blocks --
+        for i, blk in enumerate(self.dbl):
+            oi, ot = self.mod_off[("d", i, "img")], self.mod_off[("d", i, "txt")]
+            for (pk, off, T, rmap, M) in ((blk["qkv"], oi, Ti, map_i, Mi),
+                                          (blk["add_qkv"], ot, Tt, map_t, Mt)):
+                a, sa = norm_in(pk.fp8, chunk(off, 0), chunk(off, 1), T, rmap, M)
+                self._lin(pk, a, qkv, M=M, sa=sa, o_map=rmap)
+            self._run("elementwise", 0.0, 8.0 * Ms * D, _C.qk_norm_rope, q, k, blk["naq"],
+                      blk["nak"], blk["nq"], blk["nk"], Tt, blk["eps"], cos, sin, True)
+            self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
+                      attn4, None, scale, False)
+            if blk["to_out"].fp8:
+                self._run("elementwise", 0.0, 3.0 * Ms * D, _C.per_token_quant_fp8, attn, ws["aq"],
+                          ws["as_"])
+                a_src, a_s = ws["aq"], ws["as_"]
+            else:
+                a_src, a_s = attn, None
+            self._lin(blk["to_out"], a_src, joint, M=Mi, sa=a_s, a_map=map_i, o_map=map_i,
+                      residual=joint, gate=chunk(oi, 2), gate_rows=Ti)
+            self._lin(blk["to_add_out"], a_src, joint, M=Mt, sa=a_s, a_map=map_t, o_map=map_t,
+                      residual=joint, gate=chunk(ot, 2), gate_rows=Tt)
+            # feed-forward (never quantised), gate/residual folded into the second GEMM
+            for (f1, f2, off, T, rmap, M) in ((blk["ff1"], blk["ff2"], oi, Ti, map_i, Mi),
+                                              (blk["cff1"], blk["cff2"], ot, Tt, map_t, Mt)):
+                self._run("elementwise", 0.0, 4.0 * M * D, _C.layernorm_modulate, ws["xn"], joint,
+                          chunk(off, 3), chunk(off, 4), B, T, 1e-6, x_map=rmap)
+                ffh = ws["ffh"][:M]
+                self._lin_mod(f1, ws["xn"][:M], ffh, M=M, act=1)
+                self._lin_mod(f2, ffh, joint, M=M, o_map=rmap, residual=joint, gate=chunk(off, 5),
+                              gate_rows=T)
+
+        # ------------------------------------------------------------------ single blocks --
+        cat = ws["cat"]
+        catw = cat.shape[1]
+        attn_in_cat = cat.view(B, S, catw)[:, :, :D].unflatten(-1, (H, dh))
+        mlp_cols = cat[:, D:]
+        for i, blk in enumerate(self.sgl):
+            off = self.mod_off[("s", i)]
+            a, sa = norm_in(blk["qkv"].fp8, chunk(off, 0), chunk(off, 1), S, None, Ms)
+            self._lin(blk["qkv"], a, qkv, M=Ms, sa=sa)
+            self._lin(blk["mlp"], a, mlp_cols, M=Ms, sa=sa, act=1, ldo=catw)
+            self._run("elementwise", 0.0, 8.0 * Ms * D, _C.qk_norm_rope, q, k, blk["nq"], blk["nk"],
+                      blk["nq"], blk["nk"], 0, blk["eps"], cos, sin, True)
+            self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
+                      attn_in_cat, None, scale, False)
+            if blk["out"].fp8:
+                self._run("elementwise", 0.0, 3.0 * Ms * catw, _C.per_token_quant_fp8, cat,
+                          ws["cq"], ws["cs"])
+                c_src, c_s = ws["cq"], ws["cs"]
+            else:
+                c_src, c_s = cat, None
+            self._lin(blk["out"], c_src, joint, M=Ms, sa=c_s, residual=joint, gate=chunk(off, 2),
+                      gate_rows=S)
+
+        # ---- output head: AdaLayerNormContinuous (scale first) + proj_out on image rows ------
+        oo = self.mod_off[("out",)]
+        self._run("elementwise", 0.0, 4.0 * Mi * D, _C.layernorm_modulate, ws["xn"], joint,
+                  chunk(oo, 1), chunk(oo, 0), B, Ti, 1e-6, x_map=map_i)
+        out = ws["out"]
+        self._lin_mod(m.proj_out, ws["xn"][:Mi], out, M=Mi)
+        return out.view(B, Ti, -1)

@@ -1,0 +1,140 @@
+"""The denoising loop of the Flux pipeline on MI355X.
+
+Mirrors python/sglang/multimodal_gen/runtime/pipelines_core/stages/denoising.py:966-1127
+(DenoisingStage.forward), :340-350 (_build_guidance), :885-936 (timestep expansion) and
+:1350-1507 (_predict_noise_with_cfg, serial CFG), plus stages/timestep_preparation.py:58-138
+and stages/latent_preparation.py:38-105 for the inputs.  A `Req` carries one batch of samples
+that share a shape and a step count.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from functools import lru_cache
+from typing import Any, List, Optional
+
+import torch
+
+from .. import _C
+from ..layers.attention import Mi355AttentionMetadataBuilder
+from ..layers.forward_context import set_forward_context
+from ..models.scheduler import (FlowMatchEulerDiscreteScheduler, prepare_mu, prepare_sigmas)
+from . import pipeline_config as pc
+
+
+@dataclass
+class Req:
+    """The fields of pipelines_core/schedule_batch.py:42- that the denoise stage reads."""
+
+    latents: torch.Tensor                      # [B, tokens, C] packed, bf16
+    prompt_embeds: torch.Tensor                # [B, 512, 4096]
+    pooled_embeds: torch.Tensor                # [B, 768]
+    negative_prompt_embeds: Optional[torch.Tensor] = None
+    neg_pooled_embeds: Optional[torch.Tensor] = None
+    height: int = 1024
+    width: int = 1024
+    num_inference_steps: int = 50
+    guidance_scale: float = 1.0                # true CFG scale (Flux default 1.0 = off)
+    embedded_cfg_scale: float = pc.EMBEDDED_CFG_SCALE
+    request_ids: List[Any] = field(default_factory=list)
+
+    @property
+    def do_classifier_free_guidance(self) -> bool:
+        return self.guidance_scale > 1.0 and self.negative_prompt_embeds is not None
+
+    @property
+    def batch_size(self) -> int:
+        return self.latents.shape[0]
+
+
+class DenoisingStage:
+    def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None,
+                 fused: bool = True, cfg_batched: bool = True):
+        self.transformer = transformer
+        # Flux ships use_dynamic_shifting=True in its scheduler config
+        self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=True)
+        self.fused = fused
+        self.cfg_batched = cfg_batched
+        self.attn_metadata_builder = Mi355AttentionMetadataBuilder()
+        self._freqs = {}
+
+    @staticmethod
+    @lru_cache(maxsize=8)
+    def _build_guidance(batch_size, device, guidance_val):
+        """denoising.py:340-350: full(B, g, fp32).to(bf16) * 1000 (stays bf16)."""
+        return torch.full((batch_size,), guidance_val, dtype=torch.float32,
+                          device=device).to(torch.bfloat16) * 1000.0
+
+    def _freqs_cis(self, text_len, width, height, device):
+        key = (text_len, width, height, str(device))
+        if key not in self._freqs:
+            self._freqs[key] = pc.get_freqs_cis(text_len, width, height, device,
+                                                self.transformer.rotary_emb)
+        return self._freqs[key]
+
+    def prepare_timesteps(self, batch: Req, device):
+        """timestep_preparation.py:58-138 with the Flux extras: sigmas = linspace(1, 1/N, N),
+        mu from the image size."""
+        sigmas = prepare_sigmas(batch.num_inference_steps)
+        mu = prepare_mu(batch.height, batch.width, pc.VAE_SCALE_FACTOR)
+        self.scheduler.set_timesteps(sigmas=list(sigmas), mu=mu, device=device)
+        return self.scheduler.timesteps
+
+    def _dit(self, **kw):
+        return self.transformer.forward_fused(**kw) if self.fused else self.transformer(**kw)
+
+    def predict_noise_with_cfg(self, batch: Req, latent_model_input, timestep, guidance, freqs,
+                               step_index: int):
+        md = self.attn_metadata_builder.build(current_timestep=step_index)
+        with set_forward_context(current_timestep=step_index, attn_metadata=md,
+                                 forward_batch=batch):
+            if not batch.do_classifier_free_guidance:
+                return self._dit(hidden_states=latent_model_input,
+                                 encoder_hidden_states=batch.prompt_embeds,
+                                 pooled_projections=batch.pooled_embeds, timestep=timestep,
+                                 guidance=guidance, freqs_cis=freqs).clone()
+            if self.cfg_batched:
+                # cond and uncond of every request ride in ONE forward of batch 2B: rows of a
+                # batch never interact inside the DiT, so this equals two separate passes.
+                out = self._dit(
+                    hidden_states=torch.cat([latent_model_input, latent_model_input], 0),
+                    encoder_hidden_states=torch.cat([batch.prompt_embeds,
+                                                     batch.negative_prompt_embeds], 0),
+                    pooled_projections=torch.cat([batch.pooled_embeds, batch.neg_pooled_embeds], 0),
+                    timestep=torch.cat([timestep, timestep], 0),
+                    guidance=None if guidance is None else torch.cat([guidance, guidance], 0),
+                    freqs_cis=freqs)
+                cond, uncond = out.chunk(2, dim=0)
+                cond, uncond = cond.contiguous(), uncond.contiguous()
+            else:
+                cond = self._dit(hidden_states=latent_model_input,
+                                 encoder_hidden_states=batch.prompt_embeds,
+                                 pooled_projections=batch.pooled_embeds, timestep=timestep,
+                                 guidance=guidance, freqs_cis=freqs).clone()
+                uncond = self._dit(hidden_states=latent_model_input,
+                                   encoder_hidden_states=batch.negative_prompt_embeds,
+                                   pooled_projections=batch.neg_pooled_embeds, timestep=timestep,
+                                   guidance=guidance, freqs_cis=freqs).clone()
+        noise_pred = torch.empty_like(cond)
+        _C.cfg_combine(noise_pred, cond, uncond, float(batch.guidance_scale))
+        return noise_pred
+
+    @torch.no_grad()
+    def forward(self, batch: Req, num_steps: Optional[int] = None) -> Req:
+        """Runs the loop in place on `batch.latents`; `num_steps` truncates it (benchmarks)."""
+        device = batch.latents.device
+        timesteps = self.prepare_timesteps(batch, device)
+        bsz = batch.batch_size
+        guidance = (self._build_guidance(bsz, device, batch.embedded_cfg_scale)
+                    if self.transformer.config.guidance_embeds else None)
+        freqs = self._freqs_cis(batch.prompt_embeds.shape[1], batch.width, batch.height, device)
+        latents = batch.latents
+        ts_host = self.scheduler._timesteps_host
+        n = len(ts_host) if num_steps is None else min(num_steps, len(ts_host))
+        for i in range(n):
+            latent_model_input = latents.to(torch.bfloat16)
+            timestep = timesteps[i].repeat(bsz)  # sigma*1000, fp32; the model does not rescale
+            noise_pred = self.predict_noise_with_cfg(batch, latent_model_input, timestep, guidance,
+                                                     freqs, i)
+            latents = self.scheduler.step(noise_pred, ts_host[i], latents)[0]
+        batch.latents = latents
+        return batch

@@ -1,0 +1,60 @@
+"""Synthetic weights and inputs of the real shapes (no checkpoints or datasets offline)."""
+from __future__ import annotations
+
+import zlib
+from typing import Optional
+
+import torch
+
+from . import pipeline_config as pc
+from .denoise import Req
+
+
+def _seed_for(name: str, seed: int) -> int:
+    return (zlib.crc32(name.encode()) + 1000003 * seed) & 0x7FFFFFFF
+
+
+@torch.no_grad()
+def init_synthetic_weights(model, seed: int = 0, host_rng: bool = True) -> None:
+    """weights ~ N(0,1) * fan_in^-0.5, biases ~ N(0,1) * 0.02, RMSNorm weights 1.
+
+    host_rng=True draws every tensor from a CPU generator seeded by the parameter NAME, so a
+    model on any device (and the CPU oracle) gets bit-identical bf16 weights; host_rng=False
+    draws on the parameter's device (full-size benchmarking: 12 B parameters)."""
+    for name, p in model.named_parameters():
+        if p.dtype == torch.float32 and p.dim() == 1:  # RMSNorm weight
+            p.data.fill_(1.0)
+            continue
+        dev = torch.device("cpu") if host_rng else p.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(_seed_for(name, seed))
+        if p.dim() == 2:
+            w = torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) \
+                * (p.shape[1] ** -0.5)
+        else:
+            w = torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) * 0.02
+        p.data.copy_(w.to(p.dtype))
+
+
+def make_synthetic_request(batch_size: int, height: int = 1024, width: int = 1024,
+                           num_inference_steps: int = 50, device="cuda", seed: int = 0,
+                           true_cfg: bool = False, guidance_scale: float = 3.5,
+                           text_len: int = pc.TEXT_LEN, joint_dim: int = 4096,
+                           pooled_dim: int = 768, in_channels: int = 64) -> Req:
+    """Latents randn[B,C,H/8,W/8] packed to [B, tokens, 4C] (latent_preparation.py:84-95),
+    text states randn*0.1, pooled randn; generated on the host for reproducibility."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    shape = pc.prepare_latent_shape(batch_size, height, width, in_channels)
+    lat = pc.pack_latents(torch.randn(shape, generator=g)).to(torch.bfloat16)
+    emb = (torch.randn(batch_size, text_len, joint_dim, generator=g) * 0.1).to(torch.bfloat16)
+    pooled = torch.randn(batch_size, pooled_dim, generator=g).to(torch.bfloat16)
+    req = Req(latents=lat.to(device), prompt_embeds=emb.to(device), pooled_embeds=pooled.to(device),
+              height=height, width=width, num_inference_steps=num_inference_steps)
+    if true_cfg:
+        nemb = (torch.randn(batch_size, text_len, joint_dim, generator=g) * 0.1).to(torch.bfloat16)
+        npool = torch.randn(batch_size, pooled_dim, generator=g).to(torch.bfloat16)
+        req.negative_prompt_embeds = nemb.to(device)
+        req.neg_pooled_embeds = npool.to(device)
+        req.guidance_scale = guidance_scale
+    return req

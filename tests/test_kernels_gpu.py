@@ -1,0 +1,373 @@
+"""Parity of every C-ABI kernel against the CPU oracle on seeded inputs (MI355X only).
+
+Bars: bit-exact for the quantisers' fp8 bytes, scales and the pure elementwise bf16 ops;
+for ops with fp32 accumulation (GEMM, attention, norms) the results are rounded to bf16 at
+the same point as the oracle, so they may differ by accumulation order only: relative L2
+<= 1e-3 (the project tolerance) and a tiny fraction of 1-ulp bf16 flips.
+"""
+import pytest
+import torch
+
+from oracle import ops
+from sglang_diffusion_amd import _C
+from tests.helpers import assert_close_bf16, bf16_ulp_diff, mismatch_frac, rel_l2
+
+pytestmark = pytest.mark.gpu
+FP8 = torch.float8_e4m3fn
+
+
+def g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------- quant --
+@pytest.mark.parametrize("M,K,scale", [(1, 128, 1.0), (7, 3072, 3.0), (130, 15360, 0.02),
+                                        (33, 24576, 1.0), (5, 8, 1.0)])
+def test_per_token_quant_bit_exact(device, M, K, scale):
+    x = (torch.randn(M, K, generator=g(M + K)) * scale).bfloat16()
+    x[0, 0] = 0
+    if M > 2:
+        x[2] = 0  # an all-zero row: scale 0, q 0
+    qr, sr = ops.per_token_quant_fp8(x)
+    xd = x.to(device)
+    q = torch.empty(M, K, dtype=FP8, device=device)
+    s = torch.empty(M, dtype=torch.float32, device=device)
+    _C.per_token_quant_fp8(xd, q, s)
+    assert torch.equal(s.cpu(), sr)
+    assert mismatch_frac(q, qr) == 0.0
+
+
+def test_per_token_quant_strided_rows_and_empty(device):
+    big = torch.randn(16, 512, generator=g(3)).bfloat16()
+    x = big[:, :256]  # row stride 512
+    qr, sr = ops.per_token_quant_fp8(x.contiguous())
+    q = torch.empty(16, 256, dtype=FP8, device=device)
+    s = torch.empty(16, dtype=torch.float32, device=device)
+    _C.per_token_quant_fp8(big.to(device)[:, :256], q, s)
+    assert torch.equal(s.cpu(), sr) and mismatch_frac(q, qr) == 0.0
+    e = torch.empty(0, 256, dtype=torch.bfloat16, device=device)
+    _C.per_token_quant_fp8(e, torch.empty(0, 256, dtype=FP8, device=device),
+                           torch.empty(0, device=device))
+
+
+def test_per_token_quant_rejects_bad_shapes(device):
+    x = torch.zeros(4, 100, dtype=torch.bfloat16, device=device)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        _C.per_token_quant_fp8(x, torch.empty(4, 100, dtype=FP8, device=device),
+                               torch.empty(4, device=device))
+
+
+@pytest.mark.parametrize("M,K,G,colmajor", [(9, 512, 128, False), (64, 3072, 128, True),
+                                             (3, 1024, 256, False), (10, 3072, 3072, False)])
+def test_per_token_group_quant_bit_exact(device, M, K, G, colmajor):
+    x = (torch.randn(M, K, generator=g(K)) * 2).bfloat16()
+    x[0, :G] = 0  # a zero group: eps floor
+    qr, sr = ops.per_token_group_quant_fp8(x, G)
+    q = torch.empty(M, K, dtype=FP8, device=device)
+    if colmajor:
+        s = torch.empty(K // G, M, dtype=torch.float32, device=device).t()
+    else:
+        s = torch.empty(M, K // G, dtype=torch.float32, device=device)
+    _C.per_token_group_quant_fp8(x.to(device), q, s, G, 1e-10, -448.0, 448.0, False)
+    assert torch.equal(s.cpu(), sr)
+    assert mismatch_frac(q, qr) == 0.0
+
+
+def test_group_quant_ue8m0_raises(device):
+    x = torch.zeros(4, 128, dtype=torch.bfloat16, device=device)
+    with pytest.raises(RuntimeError, match="UE8M0"):
+        _C.per_token_group_quant_fp8(x, torch.empty(4, 128, dtype=FP8, device=device),
+                                     torch.empty(4, 1, device=device), 128, 1e-10, -448, 448, True)
+
+
+@pytest.mark.parametrize("n", [8, 4096 * 3 + 8, 1000003])
+def test_per_tensor_quant_bit_exact(device, n):
+    x = (torch.randn(n, generator=g(n)) * 4).bfloat16()
+    qr, sr = ops.per_tensor_quant_fp8(x)
+    q = torch.empty(n, dtype=FP8, device=device)
+    s = torch.zeros(1, dtype=torch.float32, device=device)
+    _C.per_tensor_quant_fp8(x.to(device), q, s, False)
+    assert torch.equal(s.cpu(), sr)
+    assert mismatch_frac(q, qr) == 0.0
+    # static: reuse the scale
+    q2 = torch.empty(n, dtype=FP8, device=device)
+    _C.per_tensor_quant_fp8(x.to(device), q2, s, True)
+    assert torch.equal(q2.view(torch.uint8), q.view(torch.uint8))
+
+
+# -------------------------------------------------------------------------------- GEMM --
+def _gemm_close(out, ref, tol=1e-3):
+    assert_close_bf16(out, ref, rel=tol, what="gemm")
+    assert mismatch_frac(out, ref) < 0.02  # only accumulation-order rounding flips
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(1, 16, 512, True), (17, 136, 128, False),
+                                         (257, 264, 1024, True), (512, 3072, 3072, True),
+                                         (300, 64, 2048, True), (2048, 512, 15360, False)])
+def test_fp8_scaled_mm_vs_oracle(device, M, N, K, bias):
+    """shapes after sgl-kernel/tests/test_fp8_gemm.py:17-35 (M 1..4096, N 16.., K 512..16384)."""
+    a = (torch.randn(M, K, generator=g(1)) * 3).clamp(-448, 448).to(FP8)
+    w = (torch.randn(N, K, generator=g(2)) * 3).clamp(-448, 448).to(FP8)
+    sa = torch.rand(M, generator=g(3)) * 0.02 + 1e-3
+    sb = torch.rand(N, generator=g(4)) * 0.02 + 1e-3
+    b = torch.randn(N, generator=g(5)).bfloat16() if bias else None
+    ref = ops.fp8_scaled_mm(a, w, sa, sb, b)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+    _C.fp8_scaled_mm(a.to(device), w.to(device), sa.to(device), sb.to(device),
+                     b.to(device) if bias else None, out)
+    _gemm_close(out, ref)
+
+
+def test_fp8_scaled_mm_exact_on_integer_data(device):
+    """Small integers: every product and partial sum is exact, so any operand-layout or
+    indexing slip shows as a hard mismatch.  Asymmetric operands catch transposes."""
+    M, N, K = 256, 256, 256
+    a = torch.randint(-2, 3, (M, K), generator=g(7)).float()
+    w = torch.randint(-2, 3, (N, K), generator=g(8)).float()
+    a[:, 0] = torch.arange(M).float() % 3
+    w[:, 1] = torch.arange(N).float() % 5 - 2
+    ones_m, ones_n = torch.ones(M), torch.ones(N)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+    _C.fp8_scaled_mm(a.to(FP8).to(device), w.to(FP8).to(device), ones_m.to(device),
+                     ones_n.to(device), None, out)
+    assert torch.equal(out.float().cpu(), (a @ w.t()).bfloat16().float())
+
+
+def test_fp8_scaled_mm_rejects_unaligned(device):
+    a = torch.zeros(8, 100, dtype=FP8, device=device)
+    w = torch.zeros(16, 100, dtype=FP8, device=device)
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        _C.fp8_scaled_mm(a, w, torch.ones(8, device=device), torch.ones(16, device=device), None,
+                         torch.empty(8, 16, dtype=torch.bfloat16, device=device))
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 128, 256), (130, 384, 1024), (256, 3072, 3072)])
+def test_fp8_blockwise_scaled_mm_vs_oracle(device, M, N, K):
+    """python/sglang/test/test_block_fp8.py:291-343 formula."""
+    x = (torch.randn(M, K, generator=g(11))).bfloat16()
+    wq, ws = ops.quantize_weight_block((torch.randn(N, K, generator=g(12)) * 0.2).bfloat16())
+    xq, xs = ops.per_token_group_quant_fp8(x, 128)
+    ref = ops.fp8_blockwise_scaled_mm(xq, wq, xs, ws)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+    xsd, wsd = xs.to(device), ws.to(device)
+    _C.fp8_blockwise_scaled_mm(xq.to(device), wq.to(device), xsd, wsd, out,
+                               (xsd.stride(0), xsd.stride(1)), (wsd.stride(1), wsd.stride(0)))
+    _gemm_close(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4, 9216, 3072, 0), (1, 64, 256, 0), (16, 3072, 768, 1),
+                                        (100, 3072, 64, 0), (257, 264, 192, 1),
+                                        (1024, 12288, 3072, 1), (700, 64, 3072, 0)])
+def test_linear_bf16_vs_oracle(device, M, N, K, act):
+    x = torch.randn(M, K, generator=g(21)).bfloat16()
+    w = (torch.randn(N, K, generator=g(22)) * K ** -0.5).bfloat16()
+    b = (torch.randn(N, generator=g(23)) * 0.1).bfloat16()
+    ref = ops.linear_bf16(x, w, b, "gelu_tanh" if act else None)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+    _C.linear_bf16(x.to(device), w.to(device), b.to(device), out, act)
+    # the CPU bf16 GEMM (oneDNN) accumulates in a different order: same tolerance class
+    assert_close_bf16(out, ref, rel=1e-3, what="linear_bf16")
+
+
+def test_linear_ex_rowmaps_gate_residual(device):
+    """Joint-buffer row maps + fused gate/residual epilogue == separate eager ops."""
+    B, Ti, Tt, D, N = 2, 96, 32, 256, 384
+    S = Ti + Tt
+    x = torch.randn(B * S, D, generator=g(31)).bfloat16()       # joint activations
+    w = (torch.randn(N, D, generator=g(32)) * D ** -0.5).bfloat16()
+    bias = (torch.randn(N, generator=g(33)) * 0.1).bfloat16()
+    gate = torch.randn(B, 3 * N, generator=g(34)).bfloat16()
+    res = torch.randn(B * S, N, generator=g(35)).bfloat16()      # joint residual/out
+    xq, xs = ops.per_token_quant_fp8(x)
+    wq, wsc = ops.quantize_weight_per_channel(w)
+    # oracle: image rows only
+    x3 = x.view(B, S, D)[:, Tt:]
+    y = ops.fp8_linear(x3, wq, wsc, bias)
+    exp = res.view(B, S, N).clone()
+    exp[:, Tt:] = ops.gate_residual(exp[:, Tt:], gate[:, N:2 * N], y)
+    out = res.to(device).clone()
+    gd = gate.to(device)
+    _C.linear_ex(xq.to(device), wq.to(device), out, M=B * Ti, N=N, K=D, lda=D, ldw=D, ldo=N,
+                 sa=xs.to(device), sb=wsc.to(device), bias=bias.to(device), residual=out,
+                 gate=gd[:, N:2 * N], ldg=gd.stride(0), gate_rows=Ti, a_map=(Ti, S, Tt),
+                 o_map=(Ti, S, Tt), fp8=True)
+    got = out.cpu().view(B, S, N)
+    assert torch.equal(got[:, :Tt], res.view(B, S, N)[:, :Tt]), "text rows must be untouched"
+    assert rel_l2(got[:, Tt:], exp[:, Tt:]) <= 1e-3
+
+
+# --------------------------------------------------------------------------- attention --
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D", [(1, 128, 128, 2, 2, 128), (2, 333, 333, 3, 3, 128),
+                                             (1, 1, 65, 2, 1, 128), (1, 200, 77, 4, 2, 64),
+                                             (1, 640, 640, 24, 24, 128)])
+def test_flash_attention_vs_oracle(device, B, Sq, Sk, H, Hk, D):
+    q = torch.randn(B, Sq, H, D, generator=g(41)).bfloat16()
+    k = torch.randn(B, Sk, Hk, D, generator=g(42)).bfloat16()
+    v = torch.randn(B, Sk, Hk, D, generator=g(43)).bfloat16()
+    ref, lse_ref = ops.attention(q, k, v, return_lse=True)
+    out = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=device)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=device)
+    _C.flash_attn_fwd(q.to(device), k.to(device), v.to(device), out, lse, D ** -0.5)
+    # tolerance of the reference's own FA test: 2x the bf16 round-trip error of the fp32
+    # reference (sgl-kernel/tests/test_flash_attention.py:1273-1308); P is bf16 inside the kernel
+    assert rel_l2(out, ref) <= 4e-3
+    assert (out.float().cpu() - ref.float()).abs().max() <= 2e-2
+    assert (lse.cpu() - lse_ref).abs().max() <= 1e-4
+
+
+def test_flash_attention_online_softmax_rescale(device):
+    """A spiked score late in the key sequence forces the running-max rescale branch."""
+    B, S, H, D = 1, 256, 1, 128
+    q = torch.randn(B, S, H, D, generator=g(44)).bfloat16()
+    k = torch.randn(B, S, H, D, generator=g(45)).bfloat16()
+    v = torch.randn(B, S, H, D, generator=g(46)).bfloat16()
+    k[0, 200, 0] = q[0, 17, 0] * 4  # huge score for (q=17, key=200), in the 4th KV tile
+    ref = ops.attention(q, k, v)
+    out = torch.empty_like(q, device=device)
+    _C.flash_attn_fwd(q.to(device), k.to(device), v.to(device), out, None, D ** -0.5)
+    assert rel_l2(out, ref) <= 4e-3
+    assert rel_l2(out[0, 17], ref[0, 17]) <= 1e-2
+
+
+def test_flash_attention_strided_views(device):
+    """q/k/v as slices of a fused [B,S,3,H,D] buffer, output into a wider row."""
+    B, S, H, D = 2, 130, 4, 128
+    qkv = torch.randn(B, S, 3, H, D, generator=g(47)).bfloat16()
+    ref = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+    qd = qkv.to(device)
+    wide = torch.zeros(B, S, 5 * H * D, dtype=torch.bfloat16, device=device)
+    o = wide[:, :, : H * D].unflatten(-1, (H, D))
+    _C.flash_attn_fwd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2], o, None, D ** -0.5)
+    assert rel_l2(o, ref) <= 4e-3
+    assert wide[:, :, H * D:].abs().sum().item() == 0
+
+
+# ------------------------------------------------------------------------- norm / rope --
+@pytest.mark.parametrize("rows,dim,wf32", [(37, 128, True), (5, 3072, False), (1000, 128, True)])
+def test_rmsnorm_vs_oracle(device, rows, dim, wf32):
+    x = torch.randn(rows, dim, generator=g(51)).bfloat16()
+    w = torch.rand(dim, generator=g(52)) + 0.5
+    w = w if wf32 else w.bfloat16()
+    ref = ops.rmsnorm(x, w, 1e-6)
+    out = torch.empty_like(x, device=device)
+    _C.rmsnorm(out, x.to(device), w.to(device), 1e-6)
+    assert bf16_ulp_diff(out, ref).max() <= 1
+    assert mismatch_frac(out, ref) < 5e-3
+    r = torch.randn(rows, dim, generator=g(53)).bfloat16()
+    fo, fr = ops.fused_add_rmsnorm(x, r, w, 1e-6)
+    xd, rd = x.to(device).clone(), r.to(device).clone()
+    _C.fused_add_rmsnorm(xd, rd, w.to(device), 1e-6)
+    assert torch.equal(rd.cpu(), fr)
+    assert bf16_ulp_diff(xd, fo).max() <= 1
+
+
+@pytest.mark.parametrize("D,interleaved", [(128, True), (64, True), (128, False)])
+def test_qk_norm_rope_vs_oracle(device, D, interleaved):
+    B, S, H, Tt = 2, 45, 3, 13
+    q = torch.randn(B, S, H, D, generator=g(61)).bfloat16()
+    k = torch.randn(B, S, H, D, generator=g(62)).bfloat16()
+    w = [torch.rand(D, generator=g(63 + i)) + 0.5 for i in range(4)]  # q_txt,k_txt,q_img,k_img
+    ang = torch.rand(S, D // 2, generator=g(70)) * 6.28
+    cos, sin = ang.cos(), ang.sin()
+    qr, kr = q.clone(), k.clone()
+    qt, kt = ops.qk_norm_rope(q[:, :Tt], k[:, :Tt], w[0], w[1], 1e-6, None, None)
+    qi, ki = ops.qk_norm_rope(q[:, Tt:], k[:, Tt:], w[2], w[3], 1e-6, None, None)
+    qr, kr = torch.cat([qt, qi], 1), torch.cat([kt, ki], 1)
+    fn = ops.rope_interleaved if interleaved else ops.rope_neox
+    qr, kr = fn(qr, cos, sin), fn(kr, cos, sin)
+    qd, kd = q.to(device), k.to(device)
+    _C.qk_norm_rope(qd, kd, *[t.to(device) for t in w], Tt, 1e-6, cos.to(device), sin.to(device),
+                    interleaved)
+    for got, ref in ((qd, qr), (kd, kr)):
+        assert_close_bf16(got, ref, rel=1e-3, max_ulps=1.0, what="qk_norm_rope")
+        assert mismatch_frac(got, ref) < 5e-3
+
+
+def test_rotary_embedding_cache_op_vs_oracle(device):
+    T, Hq, Hk, D, rot = 50, 4, 2, 128, 64
+    q = torch.randn(T, Hq * D, generator=g(71)).bfloat16()
+    k = torch.randn(T, Hk * D, generator=g(72)).bfloat16()
+    pos = torch.randint(0, 100, (T,), generator=g(73))
+    ang = torch.rand(100, rot // 2, generator=g(74)) * 6.28
+    cache = torch.cat([ang.cos(), ang.sin()], -1)
+    for neox in (False, True):
+        qr, kr = ops.rotary_embedding_cache(pos, q, k, D, cache, neox)
+        qd, kd = q.to(device).clone(), k.to(device).clone()
+        _C.rotary_embedding(pos.to(device), qd, kd, D, cache.to(device), neox)
+        assert_close_bf16(qd, qr, max_ulps=1.0)
+        assert_close_bf16(kd, kr, max_ulps=1.0)
+
+
+@pytest.mark.parametrize("B,T,D", [(2, 33, 3072), (1, 7, 256), (3, 5, 1536)])
+def test_layernorm_modulate_vs_oracle(device, B, T, D):
+    x = torch.randn(B, T, D, generator=g(81)).bfloat16() * 2 + 0.3
+    shift = torch.randn(B, D, generator=g(82)).bfloat16()
+    scale = torch.randn(B, D, generator=g(83)).bfloat16()
+    ref = ops.layernorm_modulate(x, shift, scale)
+    out = torch.empty(B * T, D, dtype=torch.bfloat16, device=device)
+    _C.layernorm_modulate(out, x.view(B * T, D).to(device), shift.to(device), scale.to(device), B,
+                          T, 1e-6)
+    assert_close_bf16(out.view(B, T, D), ref, max_ulps=1.0, what="layernorm_modulate")
+    assert mismatch_frac(out.view(B, T, D), ref) < 5e-3
+    # plain LayerNorm (no modulation)
+    ref0 = ops.layernorm_modulate(x, None, None)
+    _C.layernorm_modulate(out, x.view(B * T, D).to(device), None, None, B, T, 1e-6)
+    assert_close_bf16(out.view(B, T, D), ref0, max_ulps=1.0)
+    # fused quantising variant == modulate then per-token quant of ITS bf16 output
+    q = torch.empty(B * T, D, dtype=FP8, device=device)
+    s = torch.empty(B * T, dtype=torch.float32, device=device)
+    _C.layernorm_modulate(out, x.view(B * T, D).to(device), shift.to(device), scale.to(device), B,
+                          T, 1e-6)
+    _C.layernorm_modulate_quant(q, s, x.view(B * T, D).to(device), shift.to(device),
+                                scale.to(device), B, T, 1e-6)
+    qr, sr = ops.per_token_quant_fp8(out.cpu())
+    assert torch.equal(s.cpu(), sr) and mismatch_frac(q, qr) == 0.0
+
+
+def test_gate_residual_activation_exact(device):
+    B, T, D = 2, 19, 512
+    y = torch.randn(B, T, D, generator=g(91)).bfloat16()
+    r = torch.randn(B, T, D, generator=g(92)).bfloat16()
+    gate = torch.randn(B, D, generator=g(93)).bfloat16()
+    ref = ops.gate_residual(r, gate, y)
+    out = torch.empty(B * T, D, dtype=torch.bfloat16, device=device)
+    _C.gate_residual(out, r.view(B * T, D).to(device), gate.to(device), y.view(B * T, D).to(device),
+                     B, T)
+    assert torch.equal(out.cpu().view(B, T, D), ref)
+    x = (torch.randn(40, 256, generator=g(94)) * 3).bfloat16()
+    o = torch.empty_like(x, device=device)
+    _C.activation(o, x.to(device), 0)
+    assert_close_bf16(o, torch.nn.functional.silu(x), max_ulps=1.0)
+    assert mismatch_frac(o, torch.nn.functional.silu(x)) < 5e-3
+    _C.activation(o, x.to(device), 1)
+    assert_close_bf16(o, torch.nn.functional.gelu(x, approximate="tanh"), max_ulps=1.0)
+    # eager tanh implementations differ by ~1 fp32 ulp among themselves, which moves a few
+    # bf16 roundings in the cancelling tail (x << 0)
+    assert mismatch_frac(o, torch.nn.functional.gelu(x, approximate="tanh")) < 1e-2
+
+
+def test_timestep_embedding_vs_oracle(device):
+    t = torch.tensor([1000.0, 999.0, 500.5, 12.25, 0.0, 3504.0])
+    ref = ops.timestep_embedding(t, 256, True, 0.0)
+    out = torch.empty(6, 256, dtype=torch.float32, device=device)
+    _C.timestep_embedding(t.to(device), out, True, 0.0, 1.0, 10000.0)
+    # reference tolerance: atol 1e-3 (jit_kernel/tests/test_timestep_embedding.py:64)
+    assert (out.cpu() - ref).abs().max() <= 1e-3
+    outb = torch.empty(6, 256, dtype=torch.bfloat16, device=device)
+    _C.timestep_embedding(t.to(device), outb, True, 0.0, 1.0, 10000.0)
+    assert bf16_ulp_diff(outb, ref.bfloat16()).float().mean() < 0.2
+
+
+def test_euler_step_and_cfg_bit_exact(device):
+    n = 4 * 4096 * 64
+    lat = torch.randn(n, generator=g(95)).bfloat16()
+    v = torch.randn(n, generator=g(96)).bfloat16()
+    for sig, sn in ((1.0, 0.9837), (0.5, 0.4711), (0.0209, 0.0)):
+        ref = ops.euler_step(lat, v, sig, sn)
+        out = torch.empty_like(lat, device=device)
+        _C.euler_step(out, lat.to(device), v.to(device), sig, sn)
+        assert torch.equal(out.cpu(), ref)
+    ref = ops.cfg_combine(lat, v, 3.5)
+    out = torch.empty_like(lat, device=device)
+    _C.cfg_combine(out, lat.to(device), v.to(device), 3.5)
+    assert torch.equal(out.cpu(), ref)

@@ -1,0 +1,131 @@
+"""Pins the CPU oracle against outputs of the reference's own compiled CPU kernels
+(fixtures in tests/golden/ref_*.npz, minted by oracle/make_golden.py) and against the
+known-answer formulas of the reference's kernel tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops
+from tests.helpers import bf16, bf16_ulp_diff, fp8, load_golden, rel_l2
+
+
+@pytest.mark.parametrize("name", ["ref_attn_s200_h3_d128.npz", "ref_attn_s96_h2_d64.npz"])
+def test_attention_matches_reference_cpu_kernel(name):
+    z = load_golden(name)
+    q, k, v, ref = bf16(z["q"]), bf16(z["k"]), bf16(z["v"]), bf16(z["out"])
+    o = ops.attention(q[None], k[None], v[None])[0]
+    # reference's own tolerance for this kernel: bf16 1e-2 (test/srt/cpu/test_flash_attn.py, utils.py:7-11)
+    assert rel_l2(o, ref) < 4e-3
+    assert (o.float() - ref.float()).abs().max() < 1e-2
+
+
+def test_rmsnorm_matches_reference_cpu_kernel():
+    z = load_golden("ref_rmsnorm.npz")
+    x, w = bf16(z["x"]), bf16(z["w"])
+    o = ops.rmsnorm(x, w, 1e-6)
+    assert bf16_ulp_diff(o, bf16(z["out"])).max() <= 1
+    fo, fr = ops.fused_add_rmsnorm(x, bf16(z["res_in"]), w, 1e-6)
+    assert torch.equal(fr, bf16(z["fa_res"]))
+    assert bf16_ulp_diff(fo, bf16(z["fa_out"])).max() <= 1
+
+
+@pytest.mark.parametrize("neox", [0, 1])
+def test_rope_matches_reference_cpu_kernel(neox):
+    z = load_golden(f"ref_rope_neox{neox}.npz")
+    q, k, cache = bf16(z["q"]), bf16(z["k"]), bf16(z["cache"])
+    T = q.shape[0]
+    pos = torch.arange(T)
+    qo, ko = ops.rotary_embedding_cache(pos, q, k, 128, cache, bool(neox))
+    assert bf16_ulp_diff(qo, bf16(z["qo"])).max() <= 1
+    assert bf16_ulp_diff(ko, bf16(z["ko"])).max() <= 1
+    # the [B,S,H,D] interleaved form used by the DiT agrees with the cache form
+    if not neox:
+        half = cache.shape[1] // 2
+        q4 = q.view(1, T, -1, 128)
+        o4 = ops.rope_interleaved(q4, cache[:, :half].float(), cache[:, half:].float())
+        assert torch.equal(o4.view(T, -1), qo)
+
+
+def test_gelu_tanh_matches_reference_cpu_kernel():
+    z = load_golden("ref_gelu_tanh.npz")
+    x = bf16(z["x"])
+    o = torch.nn.functional.gelu(x, approximate="tanh")
+    assert bf16_ulp_diff(o, bf16(z["out"])).max() <= 1
+
+
+def test_block_fp8_weight_gemm_matches_reference_cpu_kernel():
+    """The reference CPU kernel is W8A16 (activations stay bf16): checks the weight block
+    dequantisation layout [N/128, K/128] and the GEMM."""
+    z = load_golden("ref_fp8_block_w8a16.npz")
+    a, wq = bf16(z["a"]), fp8(z["wq"])
+    ws = torch.from_numpy(z["ws"])
+    bias = torch.from_numpy(z["bias"])
+    wd = wq.float() * ws.repeat_interleave(128, 0).repeat_interleave(128, 1)
+    o = (a.float() @ wd.t() + bias).bfloat16()
+    # reference tolerance for this op: test/srt/cpu/test_gemm.py:176-218 (atol/rtol 1e-2 class)
+    assert rel_l2(o, bf16(z["out"])) < 5e-3
+    # and the W8A8 block path of the oracle stays close to it (extra activation quantisation)
+    o2 = ops.fp8_block_linear(a, wq, ws, bias.bfloat16())
+    assert rel_l2(o2, bf16(z["out"])) < 4e-2
+
+
+def test_per_token_quant_known_answers():
+    """sgl-kernel/tests/test_per_token_quant_fp8.py:14-27 formula + corner cases."""
+    x = torch.tensor([[448.0, -224.0, 1.0, 0.0], [0.0, 0.0, 0.0, 0.0],
+                      [1e-3, -2e-3, 4e-3, 8e-3]]).bfloat16()
+    q, s = ops.per_token_quant_fp8(x)
+    assert s[0].item() == 1.0 and s[1].item() == 0.0
+    assert q[0].float().tolist() == [448.0, -224.0, 1.0, 0.0]
+    assert q[1].float().abs().sum() == 0
+    assert q[2].float().abs().max() == 448.0
+    big = torch.randn(64, 256).bfloat16() * 5
+    q, s = ops.per_token_quant_fp8(big)
+    deq = q.float() * s[:, None]
+    assert rel_l2(deq, big.float()) < 0.04  # e4m3 has 3 mantissa bits
+
+
+def test_group_quant_known_answers():
+    """python/sglang/test/test_block_fp8.py:41-66."""
+    x = torch.randn(8, 512).bfloat16()
+    q, s = ops.per_token_group_quant_fp8(x, 128)
+    assert s.shape == (8, 4)
+    xr = x.float().reshape(8, 4, 128)
+    assert torch.allclose(s, xr.abs().amax(-1) / 448.0)
+    assert q.float().abs().max() <= 448
+    z = torch.zeros(1, 128).bfloat16()
+    q, s = ops.per_token_group_quant_fp8(z, 128)
+    assert s.item() == pytest.approx(1e-10 / 448.0)
+
+
+def test_fp8_scaled_mm_formula():
+    """sgl-kernel/tests/test_fp8_gemm.py:6-35."""
+    M, N, K = 16, 32, 128
+    a = torch.randn(M, K).clamp(-448, 448).to(torch.float8_e4m3fn)
+    b = torch.randn(N, K).clamp(-448, 448).to(torch.float8_e4m3fn)
+    sa, sb = torch.rand(M), torch.rand(N)
+    bias = torch.randn(N).bfloat16()
+    o = ops.fp8_scaled_mm(a, b, sa, sb, bias)
+    ref = (torch.matmul(a.float(), b.float().t()) * sa.view(-1, 1) * sb.view(1, -1) + bias).bfloat16()
+    assert torch.equal(o, ref)
+
+
+def test_euler_and_cfg_rounding_points():
+    lat = torch.randn(4096).bfloat16()
+    v = torch.randn(4096).bfloat16()
+    o = ops.euler_step(lat, v, 0.9, 0.85)
+    dt = torch.tensor(0.85) - torch.tensor(0.9)
+    manual = (lat.float() + (dt.bfloat16().float() * v.float()).bfloat16().float()).bfloat16()
+    assert torch.equal(o, manual), "dt * v must be a bf16 product with dt rounded to bf16"
+    c = ops.cfg_combine(lat, v, 3.5)
+    manual = (v.float() + (3.5 * (lat.float() - v.float()).bfloat16().float()).bfloat16().float()).bfloat16()
+    assert torch.equal(c, manual)
+
+
+def test_timestep_embedding_formula():
+    """python/sglang/jit_kernel/tests/test_timestep_embedding.py:17-47."""
+    t = torch.tensor([0.0, 1.0, 999.0])
+    e = ops.timestep_embedding(t, 256, True, 0.0)
+    assert e.shape == (3, 256)
+    assert torch.allclose(e[0, :128], torch.ones(128)) and torch.allclose(e[0, 128:], torch.zeros(128))
+    assert e[1, 0].item() == pytest.approx(np.cos(1.0), abs=1e-6)
+    assert e[1, 128].item() == pytest.approx(np.sin(1.0), abs=1e-6)
