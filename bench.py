@@ -193,39 +193,31 @@ def main():
     torch.cuda.synchronize()
     classes = {}
     for kind, flops, nbytes, e0, e1 in eng.trace:
-        c = classes.setdefault(kind, dict(ms=0.0, flops=0.0, bytes=0.0, n=0, big_ms=0.0,
-                                          big_flops=0.0, big_n=0))
-        ms = e0.elapsed_time(e1)
-        c["ms"] += ms
+        c = classes.setdefault(kind, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+        c["ms"] += e0.elapsed_time(e1)
         c["flops"] += flops
         c["bytes"] += nbytes
         c["n"] += 1
-        # launches large enough for the 256x256-tile kernel (>= 192 tiles: gemm.hip)
-        if kind == "gemm_fp8" and flops >= 2.0 * 16384 * 3072 * 3072:
-            c["big_ms"] += ms
-            c["big_flops"] += flops
-            c["big_n"] += 1
     eng.trace = None
     nsteps_traced = 2
     breakdown = {k: dict(ms_per_step=v["ms"] / nsteps_traced, launches_per_step=v["n"] // nsteps_traced,
+                         avg_launch_us=v["ms"] * 1e3 / v["n"],
                          tflops=(v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
                          gbs=(v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0)
                  for k, v in classes.items()}
-    g8 = classes.get("gemm_fp8") if args.mode == "fp8" else None
-    if g8 and g8["big_n"]:
-        ach = g8["big_flops"] / (g8["big_ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP8_TFLOPS, "traffic": None,
-                    "kernel": "gemm_kernel<fp8,256x256x128B> (fp8 W8A8 linear)",
-                    "launches_per_step": g8["big_n"] // nsteps_traced,
-                    "avg_launch_us": g8["big_ms"] * 1e3 / g8["big_n"],
-                    "flop_per_launch": g8["big_flops"] / g8["big_n"]}
-    else:
-        gb = classes["gemm_bf16"]
-        ach = gb["flops"] / (gb["ms"] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                    "kernel": "gemm_kernel<bf16> (bf16 linear)"}
+    # dominant kernel: the 256x256-tile GEMM of the mode's main dtype
+    dom = "gemm_fp8_256" if args.mode == "fp8" else "gemm_bf16_256"
+    peak = PEAK_FP8_TFLOPS if args.mode == "fp8" else PEAK_BF16_TFLOPS
+    d = classes[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None,
+                "kernel": ("gemm_kernel<1,4,2,2,4,false> (fp8 W8A8 linear, 256x256x128B tile)"
+                           if args.mode == "fp8" else
+                           "gemm_kernel<0,4,2,2,4,false> (bf16 linear, 256x256x128B tile)"),
+                "launches_per_step": d["n"] // nsteps_traced,
+                "avg_launch_us": d["ms"] * 1e3 / d["n"],
+                "flop_per_launch": d["flops"] / d["n"]}
     fl = flux_step_flops(B, n_double=cfg.num_layers, n_single=cfg.num_single_layers)
 
     if rank != 0:

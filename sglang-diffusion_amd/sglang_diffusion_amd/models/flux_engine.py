@@ -158,7 +158,10 @@ class FluxEngine:
     # ---------------------------------------------------------------------- helpers --
     def _lin(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
              gate=None, gate_rows=0, act=0, ldo=None, lda=None):
-        self._run("gemm_fp8" if pk.fp8 else "gemm_bf16", 2.0 * M * pk.N * pk.K,
+        # same tile rule as csrc/gemm.hip: the 256x256 kernel when it yields >= 192 tiles
+        big = ((M + 255) // 256) * ((pk.N + 255) // 256) >= 192
+        self._run(("gemm_fp8" if pk.fp8 else "gemm_bf16") + ("_256" if big else "_128"),
+                  2.0 * M * pk.N * pk.K,
                   (M * pk.K + pk.N * pk.K) * (1 if pk.fp8 else 2) + 2.0 * M * pk.N,
                   _C.linear_ex, a, pk.w, out, M=M, N=pk.N, K=pk.K, lda=lda or a.stride(0),
                   ldw=pk.w.stride(0), ldo=ldo or out.stride(0), sa=sa, sb=pk.s, bias=pk.b,
@@ -169,7 +172,9 @@ class FluxEngine:
         """Unquantised nn.Linear-style module (FF, embedders)."""
         w = mod.weight.data
         N, K = w.shape
-        self._run("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), _C.linear_ex, a, w,
+        big = ((M + 255) // 256) * ((N + 255) // 256) >= 192
+        self._run("gemm_bf16" + ("_256" if big else "_128"), 2.0 * M * N * K,
+                  2.0 * (M * K + N * K + M * N), _C.linear_ex, a, w,
                   out, M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldo=out.stride(0),
                   bias=mod.bias.data if mod.bias is not None else None, residual=residual,
                   gate=gate, ldg=gate.stride(0) if gate is not None else 0, gate_rows=gate_rows,
