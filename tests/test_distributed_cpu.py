@@ -1,0 +1,117 @@
+"""world_size-2 `gloo` tests of the multi-process paths: the gather of final latents with
+unequal per-rank request counts, the Ulysses all-to-all, and the data-parallel batch
+scheduler draining one queue on two ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sglang_diffusion_amd.runtime.batch_scheduler import DataParallelBatchScheduler, merge_requests
+from sglang_diffusion_amd.runtime.parallel import (gather_latents, init_distributed, shard_requests,
+                                                   ulysses_all_to_all)
+from sglang_diffusion_amd.runtime.synthetic import make_synthetic_request
+
+WORLD = 2
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, port, fn, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, w, _ = init_distributed("gloo")
+    assert (r, w) == (rank, WORLD)
+    try:
+        ret[rank] = fn(rank)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(fn):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, fn, ret)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    return dict(ret)
+
+
+def _gather_case(rank):
+    counts = [3, 1]
+    local = torch.full((counts[rank], 4, 2), float(rank + 1)) + torch.arange(counts[rank]).view(-1, 1, 1)
+    out = gather_latents(local.bfloat16(), counts)
+    return None if out is None else out.float()
+
+
+def test_gather_latents_uneven_counts():
+    ret = _run(_gather_case)
+    assert ret[1] is None
+    out = ret[0]
+    assert out.shape == (4, 4, 2)
+    assert out[:, 0, 0].tolist() == [1.0, 2.0, 3.0, 2.0]
+
+
+def _ulysses_case(rank):
+    B, S, H, D = 2, 6, 4, 8
+    full = torch.arange(B * S * H * D, dtype=torch.float32).view(B, S, H, D)
+    local = full[:, rank * S // WORLD:(rank + 1) * S // WORLD].contiguous()   # sequence shard
+    g = dist.group.WORLD
+    heads = ulysses_all_to_all(local, g, scatter_dim=2, gather_dim=1)          # -> all S, H/P heads
+    ok_fwd = torch.equal(heads, full[:, :, rank * H // WORLD:(rank + 1) * H // WORLD])
+    back = ulysses_all_to_all(heads, g, scatter_dim=1, gather_dim=2)           # inverse exchange
+    ok_back = torch.equal(back, local)
+    try:
+        ulysses_all_to_all(torch.zeros(1, 3, 3, 2), g, scatter_dim=2, gather_dim=1)
+        raised = False
+    except ValueError:
+        raised = True
+    return ok_fwd, ok_back, raised
+
+
+def test_ulysses_all_to_all_round_trip():
+    ret = _run(_ulysses_case)
+    for rank in range(WORLD):
+        assert ret[rank] == (True, True, True)
+
+
+class _FakeStage:
+    def forward(self, req, num_steps=None):
+        req.latents = req.latents * 2 + req.prompt_embeds.float().mean(dim=(1, 2)).view(-1, 1, 1)
+        return req
+
+
+def _queue():
+    return [make_synthetic_request(1 + (s % 2), height=64, width=64, num_inference_steps=2,
+                                   device="cpu", seed=s, text_len=4, joint_dim=8, pooled_dim=4)
+            for s in range(5)]
+
+
+def _dp_case(rank):
+    sch = DataParallelBatchScheduler(_FakeStage(), rank=rank, world_size=WORLD, max_samples_per_step=3)
+    for r in _queue():
+        sch.add_request(r)
+    mine = list(sch.local_slice(5))
+    out = sch.run()
+    return mine, (None if out is None else out.float())
+
+
+def test_dp_scheduler_two_ranks_equals_serial():
+    ret = _run(_dp_case)
+    assert ret[0][0] == list(shard_requests(5, WORLD, 0)) == [0, 1, 2]
+    assert ret[1][0] == [3, 4]
+    assert ret[1][1] is None
+    expect = torch.cat([_FakeStage().forward(merge_requests([r])).latents for r in _queue()], dim=0)
+    assert torch.equal(ret[0][1], expect.float())

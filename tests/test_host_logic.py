@@ -1,0 +1,230 @@
+"""Host-side logic that runs without a GPU: request sharding and micro-batch planning of the
+data-parallel batch scheduler, the flow-match schedule against the oracle's restatement, the
+quantization / attention plugin registries, latent packing, and the op-registry schemas."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flux_oracle
+from sglang_diffusion_amd.layers import attention as A
+from sglang_diffusion_amd.layers import quantization as Q
+from sglang_diffusion_amd.models.scheduler import (FlowMatchEulerDiscreteScheduler, calculate_shift,
+                                                   prepare_mu, prepare_sigmas)
+from sglang_diffusion_amd.runtime import pipeline_config as P
+from sglang_diffusion_amd.runtime.batch_scheduler import (DataParallelBatchScheduler,
+                                                          merge_requests, plan_microbatches)
+from sglang_diffusion_amd.runtime.denoise import Req
+from sglang_diffusion_amd.runtime.parallel import shard_requests
+from sglang_diffusion_amd.runtime.synthetic import make_synthetic_request
+
+
+# ------------------------------------------------------------------------- DP scheduler --
+@pytest.mark.parametrize("n,world", [(0, 8), (1, 8), (7, 8), (8, 8), (32, 8), (33, 8), (5, 2), (64, 3)])
+def test_shard_requests_partitions_the_queue(n, world):
+    parts = [shard_requests(n, world, r) for r in range(world)]
+    flat = [i for p in parts for i in p]
+    assert flat == list(range(n))                      # contiguous, ordered, complete, disjoint
+    sizes = [len(p) for p in parts]
+    assert max(sizes) - min(sizes) <= 1                # balanced
+    assert sizes == sorted(sizes, reverse=True)        # the remainder goes to the first ranks
+
+
+def _req(b=1, h=128, w=128, steps=4, cfg=False, seed=0):
+    r = make_synthetic_request(b, height=h, width=w, num_inference_steps=steps, device="cpu",
+                               seed=seed, text_len=8, joint_dim=16, pooled_dim=8)
+    if cfg:
+        r.guidance_scale = 3.5
+        r.negative_prompt_embeds = torch.zeros_like(r.prompt_embeds)
+        r.neg_pooled_embeds = torch.zeros_like(r.pooled_embeds)
+    return r
+
+
+def test_plan_microbatches_fifo_capacity_and_compat():
+    reqs = [_req(1), _req(2), _req(1, cfg=True), _req(1), _req(1, h=256, w=256), _req(3), _req(1)]
+    plans = plan_microbatches(reqs, max_samples=4)
+    # every request exactly once
+    assert sorted(i for p in plans for i in p) == list(range(len(reqs)))
+    for p in plans:
+        assert p == sorted(p)                          # FIFO inside a micro-batch
+        keys = {(reqs[i].height, reqs[i].do_classifier_free_guidance) for i in p}
+        assert len(keys) == 1                          # only compatible requests are merged
+        cost = sum(reqs[i].batch_size * (2 if reqs[i].do_classifier_free_guidance else 1) for i in p)
+        assert cost <= 4
+    assert plans[0] == [0, 1, 3]                       # 1 + 2 + 1 samples fill the first batch
+    assert [2] in plans and [4] in plans               # CFG pair and the other resolution stay apart
+    with pytest.raises(ValueError):
+        plan_microbatches([_req(5)], max_samples=4)
+    # a CFG request costs two DiT samples
+    assert plan_microbatches([_req(1, cfg=True)] * 3, max_samples=4) == [[0, 1], [2]]
+
+
+def test_merge_requests_concatenates_batch_dim():
+    a, b = _req(1, seed=1), _req(2, seed=2)
+    m = merge_requests([a, b])
+    assert m.batch_size == 3
+    assert torch.equal(m.latents[:1], a.latents) and torch.equal(m.latents[1:], b.latents)
+    assert torch.equal(m.prompt_embeds[1:], b.prompt_embeds)
+    c, d = _req(1, cfg=True, seed=3), _req(1, cfg=True, seed=4)
+    m2 = merge_requests([c, d])
+    assert m2.do_classifier_free_guidance and m2.negative_prompt_embeds.shape[0] == 2
+
+
+class _FakeStage:
+    """Stands in for the GPU denoise loop: a deterministic per-sample function of the inputs,
+    so the scheduler's slicing / merging / ordering can be checked without a device."""
+
+    def forward(self, req: Req, num_steps=None):
+        req.latents = req.latents * 2 + req.prompt_embeds.float().mean(dim=(1, 2)).view(-1, 1, 1)
+        return req
+
+
+def test_dp_scheduler_single_rank_matches_per_request_runs():
+    reqs = [_req(1, seed=s) for s in range(5)] + [_req(2, seed=9)]
+    expect = [_FakeStage().forward(merge_requests([r])).latents for r in reqs]
+    sch = DataParallelBatchScheduler(_FakeStage(), max_samples_per_step=3)
+    for r in reqs:
+        sch.add_request(r)
+    outs = sch.run()
+    assert len(sch.queue) == 0 and len(outs) == len(reqs)
+    for o, e in zip(outs, expect):
+        assert torch.equal(o, e)
+
+
+# ----------------------------------------------------------------------------- schedule --
+def test_mu_and_sigmas_follow_the_reference_rules():
+    # runtime/pipelines/flux.py:22-51: image_seq_len = (H/8)(W/8) = 16384, NOT the 4096 packed tokens
+    mu = prepare_mu(1024, 1024)
+    m = (1.15 - 0.5) / (4096 - 256)
+    assert mu == pytest.approx(16384 * m + (0.5 - m * 256), rel=1e-12)
+    assert calculate_shift(256) == pytest.approx(0.5)
+    assert calculate_shift(4096) == pytest.approx(1.15)
+    s = prepare_sigmas(50)
+    assert s.shape == (50,) and s[0] == 1.0 and s[-1] == pytest.approx(1 / 50)
+
+
+@pytest.mark.parametrize("steps,h,w", [(50, 1024, 1024), (4, 1024, 1024), (28, 512, 768), (1, 256, 256)])
+def test_scheduler_matches_oracle_schedule(steps, h, w):
+    sch = FlowMatchEulerDiscreteScheduler(shift=3.0, use_dynamic_shifting=True)
+    sch.set_timesteps(sigmas=prepare_sigmas(steps), mu=prepare_mu(h, w), device="cpu")
+    sig_ref, ts_ref = flux_oracle.flux_schedule(steps, h, w)
+    assert torch.equal(sch.sigmas.cpu(), sig_ref)
+    assert torch.equal(sch.timesteps.cpu(), ts_ref)
+    assert sch.sigmas.shape == (steps + 1,) and sch.sigmas[-1] == 0.0
+    assert sch.sigmas.dtype == torch.float32
+    # shifted sigma: e^mu / (e^mu + (1/sigma - 1))
+    mu = prepare_mu(h, w)
+    s0 = prepare_sigmas(steps)
+    expect = np.exp(mu) / (np.exp(mu) + (1 / s0 - 1))
+    np.testing.assert_allclose(sch.sigmas[:-1].numpy(), expect.astype(np.float32), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ quantization plugin --
+def test_fp8_config_from_config_and_registry():
+    cls = Q.get_quantization_config("fp8")
+    assert cls is Q.Fp8Config and cls.get_name() == "fp8"
+    cfg = cls.from_config({"quant_method": "fp8", "activation_scheme": "dynamic",
+                           "modules_to_not_convert": ["model.proj_out", "ff.net"]})
+    assert cfg.is_checkpoint_fp8_serialized and cfg.weight_block_size is None
+    assert cfg.ignored_layers == ["proj_out", "ff.net"]
+    blk = cls.from_config({"quant_method": "fp8", "activation_scheme": "dynamic",
+                           "weight_block_size": [128, 128]})
+    assert blk.weight_block_size == [128, 128]
+    with pytest.raises(ValueError):
+        Q.Fp8Config(activation_scheme="per-token")
+    with pytest.raises(ValueError):   # block quantisation needs an fp8-serialised checkpoint
+        Q.Fp8Config(is_checkpoint_fp8_serialized=False, weight_block_size=[128, 128])
+    with pytest.raises(ValueError):
+        Q.Fp8Config(is_checkpoint_fp8_serialized=True, weight_block_size=[128])
+    with pytest.raises(ValueError):
+        cls.from_config({"activation_scheme": "dynamic"})
+    with pytest.raises(ValueError):
+        Q.get_quantization_config("awq")
+
+
+def test_fp8_config_picks_the_method_per_layer():
+    from sglang_diffusion_amd.layers.linear import ReplicatedLinear
+
+    cfg = Q.Fp8Config(is_checkpoint_fp8_serialized=True, ignored_layers=["ff.net"])
+    lin = ReplicatedLinear(256, 128, quant_config=cfg, params_dtype=torch.bfloat16,
+                           prefix="transformer_blocks.0.attn.to_q")
+    assert isinstance(lin.quant_method, Q.Fp8LinearMethod)
+    assert lin.weight.dtype == torch.float8_e4m3fn and lin.weight.shape == (128, 256)
+    assert lin.weight_scale.dtype == torch.float32
+    skip = ReplicatedLinear(256, 128, quant_config=cfg, params_dtype=torch.bfloat16,
+                            prefix="transformer_blocks.0.ff.net.2")
+    assert isinstance(skip.quant_method, Q.UnquantizedLinearMethod)
+    assert skip.weight.dtype == torch.bfloat16
+    assert cfg.get_quant_method(torch.nn.LayerNorm(8), "x") is None
+    blk = Q.Fp8Config(is_checkpoint_fp8_serialized=True, weight_block_size=[128, 128])
+    lb = ReplicatedLinear(384, 256, quant_config=blk, params_dtype=torch.bfloat16,
+                          prefix="single_transformer_blocks.0.proj_mlp")
+    assert lb.weight_scale_inv.shape == (2, 3)
+    # the product path has no CPU implementation: applying on CPU tensors must raise
+    with pytest.raises(RuntimeError):
+        skip(torch.zeros(2, 256, dtype=torch.bfloat16))
+
+
+# --------------------------------------------------------------------- attention plugin --
+def test_attention_selector_and_backend_interface():
+    be = A.get_attn_backend(128, torch.bfloat16)
+    assert issubclass(be, A.AttentionBackend)
+    assert be is A.get_attn_backend(128, torch.bfloat16)            # cached
+    assert be.get_enum() in (A.AttentionBackendEnum.AITER, A.AttentionBackendEnum.FA)
+    assert issubclass(be.get_impl_cls(), A.AttentionImpl)
+    assert issubclass(be.get_builder_cls(), A.AttentionMetadataBuilder)
+    md = be.get_builder_cls()().build(current_timestep=3)
+    assert isinstance(md, be.get_metadata_cls()) and md.current_timestep == 3
+    with pytest.raises(ValueError):
+        A.get_attn_backend(128, torch.float32)
+    with pytest.raises(ValueError):
+        A.get_attn_backend(128, torch.bfloat16, (A.AttentionBackendEnum.TORCH_SDPA,))
+    with pytest.raises(ValueError):
+        A.get_attn_backend_cls_str(A.AttentionBackendEnum.TORCH_SDPA, 128, torch.bfloat16)
+    impl = be.get_impl_cls()(num_heads=4, head_size=128, softmax_scale=128 ** -0.5)
+    q = torch.zeros(1, 8, 4, 128, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):                               # CPU tensors: no fallback
+        impl.forward(q, q, q, None)
+    attn = A.USPAttention(num_heads=4, head_size=128)
+    assert attn.softmax_scale == pytest.approx(128 ** -0.5)
+
+
+# ------------------------------------------------------------------------ latent layout --
+def test_pack_unpack_latents_and_ids():
+    x = torch.randn(2, 16, 32, 48)
+    p = P.pack_latents(x)
+    assert p.shape == (2, 16 * 24, 64)
+    # token (r, c) holds the 2x2 patch [c, dy, dx] flattened (configs/pipeline_configs/flux.py:92-108)
+    assert torch.equal(p[1, 5 * 24 + 7], x[1, :, 10:12, 14:16].reshape(64))
+    back = P.unpack_latents(p, 32 * 8, 48 * 8)
+    assert torch.equal(back, x)
+    ids = P.prepare_latent_image_ids(4 * 16, 6 * 16, "cpu")     # pixel sizes -> 4 x 6 tokens
+    assert ids.shape == (24, 3) and ids[:, 0].abs().sum() == 0
+    assert ids[6 + 2].tolist() == [0.0, 1.0, 2.0]
+    assert tuple(P.prepare_latent_shape(3, 1024, 1024)) == (3, 16, 128, 128)
+
+
+# ------------------------------------------------------------------ op registry (no GPU) --
+def test_sgl_kernel_schemas_and_fake_impls():
+    import sgl_kernel
+    from sgl_kernel._ops import SCHEMAS
+
+    for name in SCHEMAS:
+        op = getattr(torch.ops.sgl_kernel, name)
+        assert str(op.default._schema).startswith(f"sgl_kernel::{name}(")
+    s = str(torch.ops.sgl_kernel.fp8_scaled_mm.default._schema)
+    assert "ScalarType out_dtype" in s and "Tensor? bias" in s
+    s = str(torch.ops.sgl_kernel.sgl_per_token_quant_fp8.default._schema)
+    assert "output_q" in s and "-> ()" in s
+    a = torch.empty(5, 256, device="meta", dtype=torch.float8_e4m3fn)
+    b = torch.empty(64, 256, device="meta", dtype=torch.float8_e4m3fn).t()
+    sc = torch.empty(5, device="meta")
+    out = torch.ops.sgl_kernel.fp8_scaled_mm(a, b, sc, torch.empty(64, device="meta"), torch.bfloat16, None)
+    assert out.shape == (5, 64) and out.dtype == torch.bfloat16 and out.device.type == "meta"
+    q = torch.empty(2, 9, 4, 128, device="meta", dtype=torch.bfloat16)
+    o, lse, *_ = sgl_kernel.flash_attn_varlen_func(q, q, q, None, None, 9, 9, return_softmax_lse=True)
+    assert o.shape == q.shape and lse.shape == (2, 4, 9) and lse.dtype == torch.float32
+    with pytest.raises(NotImplementedError):           # CPU tensors are never computed on
+        sgl_kernel.sgl_per_token_quant_fp8(torch.zeros(2, 128, dtype=torch.bfloat16),
+                                           torch.zeros(2, 128).to(torch.float8_e4m3fn), torch.zeros(2))
