@@ -46,6 +46,111 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 
+// ---- epilogue shared by the GEMM kernels (N % 8 == 0 is a launch precondition) ----
+// Two passes through LDS so that global stores are whole 128-B lines: (1) every
+// wave turns its accumulators into bf16 (scales, bias, activation) and writes
+// them as a [rows][TN*32] image into its own slice of the now idle operand
+// buffers; (2) it reads the image back row-major, 16 B per lane, applies
+// gate/residual and stores runs of TN*64 contiguous bytes per row.
+// sb_l / sa_l / bias_l: the tile's per-channel scales, per-token scales and bias in LDS.
+// The caller has made sure every wave is done with the operand tiles (barrier).
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM],
+                                              unsigned char* smem, const float* sb_l,
+                                              const float* sa_l, const unsigned short* bias_l,
+                                              int m0, int n0, int wave, int lane) {
+  const int wm = wave % WAVES_M;
+  const int wn = wave / WAVES_M;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  constexpr int ROWB = TN * 64;      // bytes per image row
+  constexpr int CHUNKS = ROWB / 16;  // 16-B chunks per row (8 or 16)
+  constexpr int RPI = 64 / CHUNKS;   // rows per wave-instruction in pass 2
+  unsigned char* ep = smem + wave * (TM * 32 * ROWB);
+  {
+    float sam[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      sam[j] = 1.f;
+      if constexpr (DT == 1 && !BLOCKSCALE) sam[j] = sa_l[wm * TM * 32 + j * 32 + r];
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      // per-channel scale and bias for this lane's 4 runs of 4 channels
+      f32x4 sbv[4], bsv[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wn * TN * 32 + i * 32 + 8 * g + 4 * h;
+        sbv[g] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (DT == 1 && !BLOCKSCALE) sbv[g] = *reinterpret_cast<const f32x4*>(sb_l + nl);
+        const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
+        bsv[g] = f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                       __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        unsigned int pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][4 * g + e];
+            if constexpr (DT == 1 && !BLOCKSCALE) v = v * sam[j] * sbv[g][e];
+            v += bsv[g][e];
+            if (p.act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
+            y[e] = v;
+          }
+          pk[g][0] = pack_bf2(y[0], y[1]);
+          pk[g][1] = pack_bf2(y[2], y[3]);
+        }
+        // widen: lanes l and l+32 exchange so each owns 8 consecutive channels
+        const int row = j * 32 + r;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            auto sw = __builtin_amdgcn_permlane32_swap(pk[g][d], pk[g + 1][d], false, false);
+            pk[g][d] = sw[0];
+            pk[g + 1][d] = sw[1];
+          }
+          const int chunk = i * 4 + g + h;
+          *reinterpret_cast<u32x4*>(ep + row * ROWB + ((chunk ^ (row & (CHUNKS - 1))) << 4)) =
+              u32x4{pk[g][0], pk[g][1], pk[g + 1][0], pk[g + 1][1]};
+        }
+      }
+    }
+  }
+  {
+    const int lc = lane % CHUNKS, lr = lane / CHUNKS;
+    const int n8 = n0 + wn * TN * 32 + lc * 8;
+    const int mw = m0 + wm * TM * 32;
+#pragma unroll 4
+    for (int it = 0; it < TM * 32 / RPI; ++it) {
+      const int row = it * RPI + lr;
+      const int m = mw + row;
+      u32x4 o = *reinterpret_cast<const u32x4*>(ep + row * ROWB + ((lc ^ (row & (CHUNKS - 1))) << 4));
+      if (m < p.M && n8 < p.N) {
+        const int64_t orow =
+            map_row32(m, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset) * p.ldo;
+        if (p.gate) {
+          const int64_t grow = (int64_t)((unsigned)m / (unsigned)p.gate_rows) * p.ldg;
+          const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + grow + n8);
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + orow + n8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y0 = __uint_as_float(o[e] << 16), y1 = __uint_as_float(o[e] & 0xffff0000u);
+            const float g0 = __uint_as_float(gv[e] << 16), g1 = __uint_as_float(gv[e] & 0xffff0000u);
+            const float r0 = __uint_as_float(rv[e] << 16), r1 = __uint_as_float(rv[e] & 0xffff0000u);
+            o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
+          }
+        }
+        *reinterpret_cast<u32x4*>(p.out + orow + n8) = o;
+      }
+    }
+  }
+}
+
 template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
@@ -153,6 +258,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   }
 
   stage(0);
+  // per-tile epilogue operands -> LDS now, so the epilogue never waits on global memory:
+  // sb[BN] | sa[BM] (fp32) | bias[BN] (bf16) behind the two operand stages.
+  float* sb_l = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
+  float* sa_l = sb_l + BN;
+  unsigned short* bias_l = reinterpret_cast<unsigned short*>(sa_l + BM);
+  {
+    for (int t = tid; t < BN; t += NW * 64) {
+      const int n = n0 + t;
+      if constexpr (DT == 1 && !BLOCKSCALE) sb_l[t] = n < p.N ? p.sb[n] : 1.f;
+      bias_l[t] = (p.bias && n < p.N) ? p.bias[n] : (unsigned short)0;
+    }
+    if constexpr (DT == 1 && !BLOCKSCALE) {
+      for (int t = tid; t < BM; t += NW * 64) {
+        const int mc = min(m0 + t, p.M - 1);
+        // per-token scales live beside the activation rows: index by the mapped A row
+        sa_l[t] = p.sa[map_row32(mc, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
+                                 p.a_map.row_offset)];
+      }
+    }
+  }
   for (int kt = 0; kt < p.ktiles; ++kt) {
     const int cur = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -235,91 +360,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
     }
   }
 
-  // ---- epilogue (N % 8 == 0 is a launch precondition) -------------------------
-  int64_t orow[TM];
-  float sam[TM];
-  bool m_ok[TM];
-  int64_t grow[TM];
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = m0 + wm * TM * 32 + j * 32 + r;
-    m_ok[j] = m < p.M;
-    const int mc = m_ok[j] ? m : p.M - 1;
-    sam[j] = 1.f;
-    // per-token scales live beside the activation rows: index by the mapped A row
-    if constexpr (DT == 1 && !BLOCKSCALE)
-      sam[j] = p.sa[map_row32(mc, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
-                              p.a_map.row_offset)];
-    orow[j] = map_row32(mc, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset) *
-              p.ldo;
-    grow[j] = p.gate ? (int64_t)((unsigned)mc / (unsigned)p.gate_rows) * p.ldg : 0;
-  }
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int nbase = n0 + wn * TN * 32 + i * 32;
-    // per-channel scale and bias for this lane's 4 runs of 4 channels
-    f32x4 sbv[4], bsv[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = nbase + 8 * g + 4 * h;
-      sbv[g] = f32x4{1.f, 1.f, 1.f, 1.f};
-      bsv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (n < p.N) {
-        if constexpr (DT == 1 && !BLOCKSCALE) sbv[g] = *reinterpret_cast<const f32x4*>(p.sb + n);
-        if (p.bias) {
-          const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + n);
-          bsv[g] = f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
-                         __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      unsigned int pk[4][2];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[i][j][4 * g + e];
-          if constexpr (DT == 1 && !BLOCKSCALE) v = v * sam[j] * sbv[g][e];
-          v += bsv[g][e];
-          if (p.act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
-          y[e] = v;
-        }
-        pk[g][0] = pack_bf2(y[0], y[1]);
-        pk[g][1] = pack_bf2(y[2], y[3]);
-      }
-      // widen: lanes l and l+32 exchange so each owns 8 consecutive channels
-#pragma unroll
-      for (int g = 0; g < 4; g += 2) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          auto sw = __builtin_amdgcn_permlane32_swap(pk[g][d], pk[g + 1][d], false, false);
-          pk[g][d] = sw[0];
-          pk[g + 1][d] = sw[1];
-        }
-        const int n8 = nbase + 8 * (g + h);
-        if (m_ok[j] && n8 < p.N) {
-          u32x4 o = u32x4{pk[g][0], pk[g][1], pk[g + 1][0], pk[g + 1][1]};
-          if (p.gate) {
-            const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + grow[j] + n8);
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + orow[j] + n8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float y0 = __uint_as_float(o[e] << 16), y1 = __uint_as_float(o[e] & 0xffff0000u);
-              const float g0 = __uint_as_float(gv[e] << 16),
-                          g1 = __uint_as_float(gv[e] & 0xffff0000u);
-              const float r0 = __uint_as_float(rv[e] << 16),
-                          r1 = __uint_as_float(rv[e] & 0xffff0000u);
-              o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
-            }
-          }
-          *reinterpret_cast<u32x4*>(p.out + orow[j] + n8) = o;
-        }
-      }
-    }
-  }
+  __syncthreads();  // every wave is done reading operand tiles
+  gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE>(p, acc, smem, sb_l, sa_l, bias_l, m0, n0,
+                                                          wave, lane);
 }
 
 // ---- small-M (<= 16 rows) bf16 linear: pure weight streaming ------------------
@@ -377,7 +420,7 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(
 template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = 2 * (BM + BN) * 128 + BN * 4 + BM * 4 + BN * 2;
   static bool attr_set = false;
   auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS>;
   if (!attr_set) {
