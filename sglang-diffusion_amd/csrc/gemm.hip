@@ -46,58 +46,51 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 
-// ---- epilogue shared by the GEMM kernels (N % 8 == 0 is a launch precondition) ----
-// Two passes through LDS so that global stores are whole 128-B lines: (1) every
-// wave turns its accumulators into bf16 (scales, bias, activation) and writes
-// them as a [rows][TN*32] image into its own slice of the now idle operand
-// buffers; (2) it reads the image back row-major, 16 B per lane, applies
-// gate/residual and stores runs of TN*64 contiguous bytes per row.
+// ---- epilogue (N % 8 == 0 is a launch precondition) ---------------------------------
+// Runs in rounds of (32 rows) x (64 channels) per wave through a 4-KiB LDS scratch so that
+// global stores are whole 128-B lines: (1) the wave turns one round of accumulators into
+// bf16 (scales, bias, activation) and writes it as a [32][64] image; (2) it reads the image
+// back row-major, 16 B per lane, applies gate/residual and stores 128 contiguous bytes per
+// row.  LDS operations of one wave execute in order, so the rounds need no barrier.
 // sb_l / sa_l / bias_l: the tile's per-channel scales, per-token scales and bias in LDS.
-// The caller has made sure every wave is done with the operand tiles (barrier).
 template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM],
-                                              unsigned char* smem, const float* sb_l,
+                                              unsigned char* scratch, const float* sb_l,
                                               const float* sa_l, const unsigned short* bias_l,
                                               int m0, int n0, int wave, int lane) {
+  static_assert(TN % 2 == 0, "rounds cover two 32-channel blocks");
   const int wm = wave % WAVES_M;
   const int wn = wave / WAVES_M;
   const int r = lane & 31;
   const int h = lane >> 5;
-  constexpr int ROWB = TN * 64;      // bytes per image row
-  constexpr int CHUNKS = ROWB / 16;  // 16-B chunks per row (8 or 16)
-  constexpr int RPI = 64 / CHUNKS;   // rows per wave-instruction in pass 2
-  unsigned char* ep = smem + wave * (TM * 32 * ROWB);
-  {
-    float sam[TM];
+  const int lc = lane & 7, lr = lane >> 3;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      sam[j] = 1.f;
-      if constexpr (DT == 1 && !BLOCKSCALE) sam[j] = sa_l[wm * TM * 32 + j * 32 + r];
-    }
+  for (int j = 0; j < TM; ++j) {
+    float sam = 1.f;
+    if constexpr (DT == 1 && !BLOCKSCALE) sam = sa_l[wm * TM * 32 + j * 32 + r];
+    const int mw = m0 + wm * TM * 32 + j * 32;
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      // per-channel scale and bias for this lane's 4 runs of 4 channels
-      f32x4 sbv[4], bsv[4];
+    for (int ip = 0; ip < TN / 2; ++ip) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = wn * TN * 32 + i * 32 + 8 * g + 4 * h;
-        sbv[g] = f32x4{1.f, 1.f, 1.f, 1.f};
-        if constexpr (DT == 1 && !BLOCKSCALE) sbv[g] = *reinterpret_cast<const f32x4*>(sb_l + nl);
-        const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
-        bsv[g] = f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
-                       __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
-      }
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const int i = 2 * ip + i2;
         unsigned int pk[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          // per-channel scale and bias of this lane's run of 4 channels
+          const int nl = wn * TN * 32 + i * 32 + 8 * g + 4 * h;
+          f32x4 sbv = f32x4{1.f, 1.f, 1.f, 1.f};
+          if constexpr (DT == 1 && !BLOCKSCALE) sbv = *reinterpret_cast<const f32x4*>(sb_l + nl);
+          const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
+          const f32x4 bsv =
+              f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                    __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
           float y[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[i][j][4 * g + e];
-            if constexpr (DT == 1 && !BLOCKSCALE) v = v * sam[j] * sbv[g][e];
-            v += bsv[g][e];
+            if constexpr (DT == 1 && !BLOCKSCALE) v = v * sam * sbv[e];
+            v += bsv[e];
             if (p.act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
             y[e] = v;
           }
@@ -105,7 +98,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           pk[g][1] = pack_bf2(y[2], y[3]);
         }
         // widen: lanes l and l+32 exchange so each owns 8 consecutive channels
-        const int row = j * 32 + r;
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
 #pragma unroll
@@ -114,43 +106,48 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             pk[g][d] = sw[0];
             pk[g + 1][d] = sw[1];
           }
-          const int chunk = i * 4 + g + h;
-          *reinterpret_cast<u32x4*>(ep + row * ROWB + ((chunk ^ (row & (CHUNKS - 1))) << 4)) =
+          const int chunk = i2 * 4 + g + h;
+          *reinterpret_cast<u32x4*>(scratch + r * 128 + ((chunk ^ (r & 7)) << 4)) =
               u32x4{pk[g][0], pk[g][1], pk[g + 1][0], pk[g + 1][1]};
         }
       }
-    }
-  }
-  {
-    const int lc = lane % CHUNKS, lr = lane / CHUNKS;
-    const int n8 = n0 + wn * TN * 32 + lc * 8;
-    const int mw = m0 + wm * TM * 32;
-#pragma unroll 4
-    for (int it = 0; it < TM * 32 / RPI; ++it) {
-      const int row = it * RPI + lr;
-      const int m = mw + row;
-      u32x4 o = *reinterpret_cast<const u32x4*>(ep + row * ROWB + ((lc ^ (row & (CHUNKS - 1))) << 4));
-      if (m < p.M && n8 < p.N) {
-        const int64_t orow =
-            map_row32(m, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset) * p.ldo;
-        if (p.gate) {
-          const int64_t grow = (int64_t)((unsigned)m / (unsigned)p.gate_rows) * p.ldg;
-          const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + grow + n8);
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + orow + n8);
+      const int n8 = n0 + wn * TN * 32 + ip * 64 + lc * 8;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float y0 = __uint_as_float(o[e] << 16), y1 = __uint_as_float(o[e] & 0xffff0000u);
-            const float g0 = __uint_as_float(gv[e] << 16), g1 = __uint_as_float(gv[e] & 0xffff0000u);
-            const float r0 = __uint_as_float(rv[e] << 16), r1 = __uint_as_float(rv[e] & 0xffff0000u);
-            o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + lr;
+        const int m = mw + row;
+        u32x4 o = *reinterpret_cast<const u32x4*>(scratch + row * 128 + ((lc ^ (row & 7)) << 4));
+        if (m < p.M && n8 < p.N) {
+          const int64_t orow =
+              map_row32(m, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset) *
+              p.ldo;
+          if (p.gate) {
+            const int64_t grow = (int64_t)((unsigned)m / (unsigned)p.gate_rows) * p.ldg;
+            const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + grow + n8);
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + orow + n8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y0 = __uint_as_float(o[e] << 16), y1 = __uint_as_float(o[e] & 0xffff0000u);
+              const float g0 = __uint_as_float(gv[e] << 16),
+                          g1 = __uint_as_float(gv[e] & 0xffff0000u);
+              const float r0 = __uint_as_float(rv[e] << 16),
+                          r1 = __uint_as_float(rv[e] & 0xffff0000u);
+              o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
+            }
           }
+          *reinterpret_cast<u32x4*>(p.out + orow + n8) = o;
         }
-        *reinterpret_cast<u32x4*>(p.out + orow + n8) = o;
       }
     }
   }
 }
 
+// Persistent GEMM: the grid holds as many workgroups as fit on the chip at once and each
+// walks the output tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  The operand stages
+// keep alternating across tile boundaries, so when a tile's K loop ends the stage it did NOT
+// use last is idle: the first K tile of the NEXT output tile is sent there by LDS-DMA before
+// the epilogue starts and lands underneath it, and the stage used last becomes the
+// epilogue's scratch (one 4-KiB slice per wave) and table area.
 template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
@@ -160,6 +157,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   constexpr int NPIECE = (BM + BN) / 8 / NW;  // 1-KiB LDS-DMA pieces per wave per K tile
   static_assert((BM + BN) / 8 % NW == 0, "pieces must divide over waves");
   constexpr int KSTEPS = DT == 0 ? 4 : 2;
+  constexpr int SCRATCH_WAVE = 32 * 128;
+  constexpr int TABLE_OFF = NW * SCRATCH_WAVE;
+  static_assert(TABLE_OFF + BN * 4 + BM * 4 + BN * 2 <= STAGE_BYTES, "scratch + tables fit a stage");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -169,49 +169,47 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   const int wm = wave % WAVES_M;
   const int wn = wave / WAVES_M;
 
-  // ---- workgroup -> output tile: XCD-contiguous chunks, 8-row groups ------
+  // ---- virtual block id -> output tile: XCD-contiguous chunks, 8-row groups -------
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    // blocks b and b+8 share an XCD (and its L2): give each XCD a contiguous
-    // range of tile ids.  Bijective for any nwg.
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GROUP = 8;
-  const int group_sz = GROUP * tiles_n;
-  const int gidx = bid / group_sz;
-  const int first_m = gidx * GROUP;
-  const int gm = min(tiles_m - first_m, GROUP);
-  const int in_g = bid - gidx * group_sz;
-  const int tile_m = first_m + in_g % gm;
-  const int tile_n = in_g / gm;
-  const int m0 = tile_m * BM;
-  const int n0 = tile_n * BN;
+  auto tile_of = [&](int vb, int& m0, int& n0) {
+    // ids b and b+8 run on one XCD (and share its L2): give each XCD a contiguous range
+    // of tile ids.  Bijective for any nwg.
+    const int q = nwg >> 3, rr = nwg & 7, xcd = vb & 7;
+    const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (vb >> 3);
+    constexpr int GROUP = 8;
+    const int group_sz = GROUP * tiles_n;
+    const int gidx = bid / group_sz;
+    const int first_m = gidx * GROUP;
+    const int gm = min(tiles_m - first_m, GROUP);
+    const int in_g = bid - gidx * group_sz;
+    m0 = (first_m + in_g % gm) * BM;
+    n0 = (in_g / gm) * BN;
+  };
 
   // ---- per-lane LDS-DMA source pointers (advance 128 B per K tile) ---------
   const unsigned char* src[NPIECE];
+  auto set_src = [&](int m0, int n0) {
 #pragma unroll
-  for (int i = 0; i < NPIECE; ++i) {
-    const int piece = wave + i * NW;
-    const int row = piece * 8 + (lane >> 3);  // row inside [X tile | W tile]
-    const int pc = lane & 7;
-    const int lc = pc ^ ((row >> 1) & 7);
-    if (piece < BM / 8) {
-      int64_t gmrow = m0 + row;
-      if (gmrow >= p.M) gmrow = p.M - 1;
-      gmrow = map_row32((int)gmrow, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
-                        p.a_map.row_offset);
-      src[i] = p.a + gmrow * p.lda_b + lc * 16;
-    } else {
-      int64_t gnrow = n0 + (row - BM);
-      if (gnrow >= p.N) gnrow = p.N - 1;
-      src[i] = p.w + gnrow * p.ldw_b + lc * 16;
+    for (int i = 0; i < NPIECE; ++i) {
+      const int piece = wave + i * NW;
+      const int row = piece * 8 + (lane >> 3);  // row inside [X tile | W tile]
+      const int pc = lane & 7;
+      const int lc = pc ^ ((row >> 1) & 7);
+      if (piece < BM / 8) {
+        int64_t gmrow = m0 + row;
+        if (gmrow >= p.M) gmrow = p.M - 1;
+        gmrow = map_row32((int)gmrow, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
+                          p.a_map.row_offset);
+        src[i] = p.a + gmrow * p.lda_b + lc * 16;
+      } else {
+        int64_t gnrow = n0 + (row - BM);
+        if (gnrow >= p.N) gnrow = p.N - 1;
+        src[i] = p.w + gnrow * p.ldw_b + lc * 16;
+      }
     }
-  }
-
+  };
   auto stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
@@ -220,6 +218,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
                                        (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16, 0,
                                        0);
       src[i] += 128;
+    }
+  };
+
+  // per-tile epilogue operands, fetched into registers at tile start
+  float sb_reg = 1.f, sa_reg = 1.f;
+  unsigned short bias_reg = 0;
+  auto load_tables = [&](int m0, int n0) {
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if constexpr (DT == 1 && !BLOCKSCALE) sb_reg = n < p.N ? p.sb[n] : 1.f;
+      bias_reg = (p.bias && n < p.N) ? p.bias[n] : (unsigned short)0;
+    }
+    if constexpr (DT == 1 && !BLOCKSCALE) {
+      if (tid < BM) {
+        const int mc = min(m0 + tid, p.M - 1);
+        // per-token scales live beside the activation rows: index by the mapped A row
+        sa_reg = p.sa[map_row32(mc, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
+                                p.a_map.row_offset)];
+      }
     }
   };
 
@@ -235,134 +252,145 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   }
   const int x_row_off = (wm * TM * 32 + r) * 128;
   const int w_row_off = BM * 128 + (wn * TN * 32 + r) * 128;
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
   const int unit_scale = 0x7f7f7f7f;  // E8M0 127 = 2^0 in every byte
 
-  // block-scaled variant: scale row pointers
-  const float* sa_row[TM];
-  if constexpr (BLOCKSCALE) {
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      int64_t m = m0 + wm * TM * 32 + j * 32 + r;
-      if (m >= p.M) m = p.M - 1;
-      sa_row[j] = p.sa + m * p.sa_sm;
-    }
-  }
-
+  int vb = blockIdx.x;
+  int m0, n0;
+  tile_of(vb, m0, n0);
+  set_src(m0, n0);
+  load_tables(m0, n0);
+  int g = 0;  // K tiles consumed so far by this workgroup: stage parity runs across tiles
   stage(0);
-  // per-tile epilogue operands -> LDS now, so the epilogue never waits on global memory:
-  // sb[BN] | sa[BM] (fp32) | bias[BN] (bf16) behind the two operand stages.
-  float* sb_l = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
-  float* sa_l = sb_l + BN;
-  unsigned short* bias_l = reinterpret_cast<unsigned short*>(sa_l + BM);
-  {
-    for (int t = tid; t < BN; t += NW * 64) {
-      const int n = n0 + t;
-      if constexpr (DT == 1 && !BLOCKSCALE) sb_l[t] = n < p.N ? p.sb[n] : 1.f;
-      bias_l[t] = (p.bias && n < p.N) ? p.bias[n] : (unsigned short)0;
-    }
-    if constexpr (DT == 1 && !BLOCKSCALE) {
-      for (int t = tid; t < BM; t += NW * 64) {
-        const int mc = min(m0 + t, p.M - 1);
-        // per-token scales live beside the activation rows: index by the mapped A row
-        sa_l[t] = p.sa[map_row32(mc, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
-                                 p.a_map.row_offset)];
-      }
-    }
-  }
-  for (int kt = 0; kt < p.ktiles; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < p.ktiles) stage(cur ^ 1);
-    const unsigned char* sbase = smem + cur * STAGE_BYTES;
 
-    f32x16 part[TN][TM];
+  while (true) {
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // block-scaled variant: scale row pointers
+    const float* sa_row[TM];
     if constexpr (BLOCKSCALE) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) part[i][j][e] = 0.f;
+      for (int j = 0; j < TM; ++j) {
+        int64_t m = m0 + wm * TM * 32 + j * 32 + r;
+        if (m >= p.M) m = p.M - 1;
+        sa_row[j] = p.sa + m * p.sa_sm;
+      }
     }
 
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      // keep one K step's fragments live at a time (256-VGPR budget at 2 waves/SIMD)
-      if constexpr (DT == 1 && TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DT == 0) {
-        bf16x8 af[TN], bfr[TM];
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-          af[i] = *reinterpret_cast<const bf16x8*>(sbase + w_row_off + i * 32 * 128 + coff[s]);
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          bfr[j] = *reinterpret_cast<const bf16x8*>(sbase + x_row_off + j * 32 * 128 + coff[s]);
+    for (int kt = 0; kt < p.ktiles; ++kt, ++g) {
+      const int cur = g & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < p.ktiles) stage(cur ^ 1);
+      const unsigned char* sbase = smem + cur * STAGE_BYTES;
+
+      f32x16 part[TN][TM];
+      if constexpr (BLOCKSCALE) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
           for (int j = 0; j < TM; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      } else {
-        i32x8 af[TN], bfr[TM];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const unsigned char* pa = sbase + w_row_off + i * 32 * 128;
-          i32x4 lo = *reinterpret_cast<const i32x4*>(pa + coff[s]);
-          i32x4 hi = *reinterpret_cast<const i32x4*>(pa + (coff[s] ^ 16));
-          af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
+            for (int e = 0; e < 16; ++e) part[i][j][e] = 0.f;
+      }
+
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const unsigned char* pb = sbase + x_row_off + j * 32 * 128;
-          i32x4 lo = *reinterpret_cast<const i32x4*>(pb + coff[s]);
-          i32x4 hi = *reinterpret_cast<const i32x4*>(pb + (coff[s] ^ 16));
-          bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
+      for (int s = 0; s < KSTEPS; ++s) {
+        // keep one K step's fragments live at a time (256-VGPR budget at 2 waves/SIMD)
+        if constexpr (DT == 1 && TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DT == 0) {
+          bf16x8 af[TN], bfr[TM];
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+          for (int i = 0; i < TN; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(sbase + w_row_off + i * 32 * 128 + coff[s]);
+#pragma unroll
+          for (int j = 0; j < TM; ++j)
+            bfr[j] = *reinterpret_cast<const bf16x8*>(sbase + x_row_off + j * 32 * 128 + coff[s]);
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else {
+          i32x8 af[TN], bfr[TM];
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            const unsigned char* pa = sbase + w_row_off + i * 32 * 128;
+            i32x4 lo = *reinterpret_cast<const i32x4*>(pa + coff[s]);
+            i32x4 hi = *reinterpret_cast<const i32x4*>(pa + (coff[s] ^ 16));
+            af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
-            if constexpr (BLOCKSCALE) {
-              part[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                  af[i], bfr[j], part[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
-            } else {
-              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                  af[i], bfr[j], acc[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
-            }
+            const unsigned char* pb = sbase + x_row_off + j * 32 * 128;
+            i32x4 lo = *reinterpret_cast<const i32x4*>(pb + coff[s]);
+            i32x4 hi = *reinterpret_cast<const i32x4*>(pb + (coff[s] ^ 16));
+            bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              if constexpr (BLOCKSCALE) {
+                part[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                    af[i], bfr[j], part[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
+              } else {
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                    af[i], bfr[j], acc[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
+              }
+            }
+        }
       }
-    }
-    if constexpr (BLOCKSCALE) {
-      // one K tile == one 128-wide scale block
+      if constexpr (BLOCKSCALE) {
+        // one K tile == one 128-wide scale block
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        int nb = (n0 + wn * TN * 32 + i * 32) >> 7;
-        const int nb_max = (p.N - 1) >> 7;
-        if (nb > nb_max) nb = nb_max;
-        const float sbv = p.sb[kt * p.sb_sk + nb * p.sb_sn];
+        for (int i = 0; i < TN; ++i) {
+          int nb = (n0 + wn * TN * 32 + i * 32) >> 7;
+          const int nb_max = (p.N - 1) >> 7;
+          if (nb > nb_max) nb = nb_max;
+          const float sbv = p.sb[kt * p.sb_sk + nb * p.sb_sn];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const float f = sa_row[j][kt * p.sa_sk] * sbv;
+          for (int j = 0; j < TM; ++j) {
+            const float f = sa_row[j][kt * p.sa_sk] * sbv;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][j][e] += part[i][j][e] * f;
+            for (int e = 0; e < 16; ++e) acc[i][j][e] += part[i][j][e] * f;
+          }
         }
       }
     }
-  }
 
-  __syncthreads();  // every wave is done reading operand tiles
-  gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE>(p, acc, smem, sb_l, sa_l, bias_l, m0, n0,
-                                                          wave, lane);
+    // ---- tile done: park the tables, prefetch the next tile, run the epilogue ----------
+    const int lastb = (g - 1) & 1;
+    __syncthreads();  // every wave is done reading operand stages
+    unsigned char* area = smem + lastb * STAGE_BYTES;
+    float* sb_l = reinterpret_cast<float*>(area + TABLE_OFF);
+    float* sa_l = sb_l + BN;
+    unsigned short* bias_l = reinterpret_cast<unsigned short*>(sa_l + BM);
+    if (tid < BN) {
+      sb_l[tid] = sb_reg;
+      bias_l[tid] = bias_reg;
+    }
+    if (tid < BM) sa_l[tid] = sa_reg;
+    const int em0 = m0, en0 = n0;
+    const int nvb = vb + (int)gridDim.x;
+    const bool more = nvb < nwg;
+    if (more) {
+      tile_of(nvb, m0, n0);
+      set_src(m0, n0);
+      stage(lastb ^ 1);  // first K tile of the next output tile, in flight under the epilogue
+      load_tables(m0, n0);
+    }
+    __syncthreads();  // tables visible
+    gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE>(p, acc, area + wave * SCRATCH_WAVE, sb_l,
+                                                            sa_l, bias_l, em0, en0, wave, lane);
+    if (!more) break;
+    vb = nvb;
+  }
 }
 
 // ---- small-M (<= 16 rows) bf16 linear: pure weight streaming ------------------
@@ -417,10 +445,24 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(
   }
 }
 
+// workgroups of one kernel that are resident at once: CUs x (workgroups per CU by LDS)
+int resident_workgroups(int lds_bytes) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
+  return cus * per_cu;
+}
+
 template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-  constexpr int LDS = 2 * (BM + BN) * 128 + BN * 4 + BM * 4 + BN * 2;
+  constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS>;
   if (!attr_set) {
@@ -433,7 +475,8 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid((unsigned)(tiles_m * tiles_n)), block(WAVES_M * WAVES_N * 64);
+  const int nwg = tiles_m * tiles_n;
+  dim3 grid((unsigned)min(nwg, resident_workgroups(LDS))), block(WAVES_M * WAVES_N * 64);
   hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
   MI355_CHECK_LAUNCH("gemm");
   return MI355_OK;
