@@ -139,6 +139,12 @@ typedef struct {
   mi355_rowmap a_map, o_map;
   int fp8;
   int act;
+  /* output columns [f16_begin, f16_end) are stored as IEEE half instead of bf16: the value is
+   * first rounded to bf16 (the linear's result, as always) and that bf16 is then written in
+   * half format, which is exact for 2^-14 <= |y| <= 65504 (larger saturates, smaller goes
+   * subnormal).  Used for the V third of a fused q|k|v projection that feeds
+   * mi355_flash_attn_fwd_f16v.  Both multiples of 32; begin == end disables. */
+  int64_t f16_begin, f16_end;
 } mi355_linear_args;
 int mi355_linear_ex(const mi355_linear_args* args, void* stream);
 
@@ -159,6 +165,22 @@ int mi355_flash_attn_fwd(const void* q, const void* k, const void* v, void* out,
                          int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb,
                          int64_t v_ss, int64_t v_sh, int64_t o_sb, int64_t o_ss,
                          int64_t o_sh, float softmax_scale, int causal, void* stream);
+
+/* Same computation with V given in IEEE half and the probabilities rounded to half (11
+ * significant bits) instead of bf16 (8) before the P.V product: the result is closer to the
+ * fp32-softmax reference (SDPAImpl on CPU) than the bf16-P form every flash kernel uses.  q, k
+ * and out stay bf16.  v comes from mi355_bf16_to_f16 or from mi355_linear_ex's f16 columns. */
+int mi355_flash_attn_fwd_f16v(const void* q, const void* k, const void* v, void* out,
+                              float* lse, int64_t B, int64_t Sq, int64_t Sk, int64_t H,
+                              int64_t Hk, int64_t D, int64_t q_sb, int64_t q_ss, int64_t q_sh,
+                              int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t v_sb,
+                              int64_t v_ss, int64_t v_sh, int64_t o_sb, int64_t o_ss,
+                              int64_t o_sh, float softmax_scale, int causal, void* stream);
+
+/* y[r][c] = half(x[r][c]) for a bf16 matrix with row strides ldx / ldy (elements);
+ * cols % 8 == 0.  Exact inside half's normal range, saturating at +-65504. */
+int mi355_bf16_to_f16(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx,
+                      int64_t ldy, void* stream);
 
 /* ------------------------------------------------------- norms and rope --
  * rmsnorm(Tensor! output, Tensor input, Tensor weight, float eps, bool pdl)

@@ -123,7 +123,14 @@ class FluxOracle:
         o = ops.attention(q, k, v).flatten(2, 3)
         if has_added:
             tl = enc.shape[1]
-            eo, o = o[:, :tl], o[:, tl:]
+            # The reference hands `split_with_sizes` views to the two output projections
+            # (models/dits/flux.py:402-413).  At batch 1, the batch its scheduler runs, those
+            # views are contiguous and F.linear fuses the bias into the matmul epilogue (one
+            # rounding), and the fp8 path always fuses it.  At batch > 1 ATen's linear() falls
+            # back to matmul + add_ for a non-contiguous 3-D input (two roundings) in bf16 mode
+            # and the fp8 path's `input.view(-1, K)` raises; that batch-size artefact is not part
+            # of the algorithm, so the oracle uses the batch-1 arithmetic at every batch size.
+            eo, o = o[:, :tl].contiguous(), o[:, tl:].contiguous()
             o = self.lin(pre + ".to_out.0", o)
             eo = self.lin(pre + ".to_add_out", eo)
             return o, eo

@@ -21,6 +21,8 @@
 // address.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -28,6 +30,9 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 hw_f16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 struct AttnParams {
   const unsigned short* q;
@@ -44,7 +49,9 @@ __device__ __forceinline__ int k_swz(int key) { return key & 15; }
 __device__ __forceinline__ int v_swz(int key) { return ((key & 3) << 2) | ((key >> 2) & 3); }
 
 // D = head size (128 or 64).  KV tile = 64 keys.
-template <int D, bool TRREAD>
+// F16: V holds IEEE half values and P is rounded to half (11 significant bits instead of
+// bf16's 8) before the PV product; Q, K and the output stay bf16.
+template <int D, bool TRREAD, bool F16>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int KV = 64;
   constexpr int ROWB = D * 2;                // bytes per K/V row
@@ -186,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const float mc = m_new * c;
     m_run = m_new;
     float rs = 0.f;
-    bf16x8 pf[2][2];
+    typedef typename std::conditional<F16, f16x8, bf16x8>::type pfrag_t;
+    pfrag_t pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       float pe[16];
@@ -198,7 +206,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[kb][st][j] = (__bf16)pe[8 * st + j];
+        for (int j = 0; j < 8; ++j) {
+          if constexpr (F16) {
+            pf[kb][st][j] = (_Float16)pe[8 * st + j];
+          } else {
+            pf[kb][st][j] = (__bf16)pe[8 * st + j];
+          }
+        }
     }
     l_run = l_run * alpha + rs;
 #pragma unroll
@@ -213,22 +227,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int d = 0; d < DVB; ++d) {
-          bf16x8 vf;
           if constexpr (TRREAD) {
-            bf16x4 tv[2];
+            int off[2];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
               const int key = kb * 32 + st * 16 + half * 8 + 4 * hh + qq;  // row this lane addresses
               const int col = d * 32 + g2 * 16 + 4 * pp;                    // first of 4 columns
               const int ch = col >> 3;
-              const int off =
+              off[half] =
                   key * ROWB + (((ch ^ (v_swz(key) & (CPR - 1)))) << 4) + ((col & 7) << 1);
-              tv[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                  (__attribute__((address_space(3))) bf16x4*)(vt + off));
             }
-            vf = __builtin_shufflevector(tv[0], tv[1], 0, 1, 2, 3, 4, 5, 6, 7);
-          } else {
+            if constexpr (F16) {
+              const f16x4 t0 = __builtin_bit_cast(
+                  f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                             (__attribute__((address_space(3))) hw_f16x4*)(vt + off[0])));
+              const f16x4 t1 = __builtin_bit_cast(
+                  f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                             (__attribute__((address_space(3))) hw_f16x4*)(vt + off[1])));
+              const f16x8 vf = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+              oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][st], oacc[d], 0, 0, 0);
+            } else {
+              const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                  (__attribute__((address_space(3))) bf16x4*)(vt + off[0]));
+              const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                  (__attribute__((address_space(3))) bf16x4*)(vt + off[1]));
+              const bf16x8 vf = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+              oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][st], oacc[d], 0, 0, 0);
+            }
+          } else if constexpr (!F16) {
             // debug path: element gathers, same image
+            bf16x8 vf;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
               const int key = kb * 32 + st * 16 + (jj >> 2) * 8 + 4 * hh + (jj & 3);
@@ -237,8 +265,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
                               ((col & 7) << 1);
               vf[jj] = __builtin_bit_cast(__bf16, *reinterpret_cast<const unsigned short*>(vt + off));
             }
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][st], oacc[d], 0, 0, 0);
           }
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][st], oacc[d], 0, 0, 0);
         }
   }
 
@@ -277,11 +305,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
-template <int D, bool TRREAD>
+template <int D, bool TRREAD, bool F16>
 int launch_attn(const AttnParams& p, hipStream_t st) {
   constexpr int LDS = 2 * 2 * 64 * D * 2;
   static bool attr_set = false;
-  auto kfn = attn_fwd_kernel<D, TRREAD>;
+  auto kfn = attn_fwd_kernel<D, TRREAD, F16>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -299,13 +327,12 @@ int launch_attn(const AttnParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mi355_flash_attn_fwd(const void* q, const void* k, const void* v, void* out,
-                                    float* lse, int64_t B, int64_t Sq, int64_t Sk, int64_t H,
-                                    int64_t Hk, int64_t D, int64_t q_sb, int64_t q_ss,
-                                    int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
-                                    int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
-                                    int64_t o_ss, int64_t o_sh, float softmax_scale, int causal,
-                                    void* stream) {
+static int attn_entry(const void* q, const void* k, const void* v, void* out, float* lse,
+                      int64_t B, int64_t Sq, int64_t Sk, int64_t H, int64_t Hk, int64_t D,
+                      int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
+                      int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
+                      int64_t o_ss, int64_t o_sh, float softmax_scale, int causal, bool v_f16,
+                      void* stream) {
   MI355_REQUIRE(q && k && v && out, "flash_attn_fwd: null pointer");
   if (causal) {
     mi355_set_error("flash_attn_fwd: causal masking is not built (the DiT path is non-causal)");
@@ -342,7 +369,31 @@ extern "C" int mi355_flash_attn_fwd(const void* q, const void* k, const void* v,
   p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
+  if (v_f16) return D == 128 ? launch_attn<128, true, true>(p, st) : launch_attn<64, true, true>(p, st);
   static const bool no_tr = getenv("MI355_ATTN_NO_TR") != nullptr;  // debugging aid
-  if (no_tr) return D == 128 ? launch_attn<128, false>(p, st) : launch_attn<64, false>(p, st);
-  return D == 128 ? launch_attn<128, true>(p, st) : launch_attn<64, true>(p, st);
+  if (no_tr)
+    return D == 128 ? launch_attn<128, false, false>(p, st) : launch_attn<64, false, false>(p, st);
+  return D == 128 ? launch_attn<128, true, false>(p, st) : launch_attn<64, true, false>(p, st);
+}
+
+extern "C" int mi355_flash_attn_fwd(const void* q, const void* k, const void* v, void* out,
+                                    float* lse, int64_t B, int64_t Sq, int64_t Sk, int64_t H,
+                                    int64_t Hk, int64_t D, int64_t q_sb, int64_t q_ss,
+                                    int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+                                    int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
+                                    int64_t o_ss, int64_t o_sh, float softmax_scale, int causal,
+                                    void* stream) {
+  return attn_entry(q, k, v, out, lse, B, Sq, Sk, H, Hk, D, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb,
+                    v_ss, v_sh, o_sb, o_ss, o_sh, softmax_scale, causal, false, stream);
+}
+
+extern "C" int mi355_flash_attn_fwd_f16v(const void* q, const void* k, const void* v, void* out,
+                                         float* lse, int64_t B, int64_t Sq, int64_t Sk, int64_t H,
+                                         int64_t Hk, int64_t D, int64_t q_sb, int64_t q_ss,
+                                         int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+                                         int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
+                                         int64_t o_ss, int64_t o_sh, float softmax_scale,
+                                         int causal, void* stream) {
+  return attn_entry(q, k, v, out, lse, B, Sq, Sk, H, Hk, D, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb,
+                    v_ss, v_sh, o_sb, o_ss, o_sh, softmax_scale, causal, true, stream);
 }

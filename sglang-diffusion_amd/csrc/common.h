@@ -58,6 +58,16 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
 
 // ---- f32 -> fp8 e4m3fn (OCP on gfx950), round-to-nearest-even ---------------
 // v_cvt_pk_fp8_f32 converts two floats into two bytes of a dword.
+// two floats -> bf16 (round to nearest even, the linear's result) -> the same values in IEEE
+// half, packed lo | hi << 16.  Exact for bf16 values inside half's normal range.
+__device__ __forceinline__ unsigned int pack_bf2_as_f16(float lo, float hi) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const float a = fminf(fmaxf(rbf(lo), -65504.f), 65504.f);
+  const float b = fminf(fmaxf(rbf(hi), -65504.f), 65504.f);
+  const h2 v = h2{(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned int, v);
+}
+
 __device__ __forceinline__ unsigned int cvt4_fp8(float a, float b, float c, float d) {
   int w = 0;
   w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);

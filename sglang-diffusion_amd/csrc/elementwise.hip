@@ -725,3 +725,40 @@ extern "C" int mi355_cfg_combine(void* out, const void* cond, const void* uncond
   MI355_CHECK_LAUNCH("cfg_combine");
   return MI355_OK;
 }
+
+// ---- bf16 -> half (V operand of the half-precision P.V attention) --------------------
+namespace {
+__global__ __launch_bounds__(256) void bf16_to_f16_kernel(const unsigned short* __restrict__ x,
+                                                           unsigned short* __restrict__ y,
+                                                           int64_t rows, int cols8, int64_t ldx,
+                                                           int64_t ldy) {
+  const int64_t total = rows * cols8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols8;
+    const int c = (int)(i - r * cols8) * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ldx + c);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack_bf2_as_f16(__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u));
+    *reinterpret_cast<u32x4*>(y + r * ldy + c) = o;
+  }
+}
+}  // namespace
+
+extern "C" int mi355_bf16_to_f16(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx,
+                                 int64_t ldy, void* stream) {
+  MI355_REQUIRE(rows >= 0 && cols >= 0, "bf16_to_f16: bad shape");
+  if (rows == 0 || cols == 0) return MI355_OK;
+  MI355_REQUIRE(x && y, "bf16_to_f16: null pointer");
+  MI355_REQUIRE(cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+                    ((uintptr_t)y % 16) == 0,
+                "bf16_to_f16: cols and strides must be multiples of 8, pointers 16-byte aligned");
+  MI355_REQUIRE(cols / 8 < (1ll << 31), "bf16_to_f16: row too long");
+  const int64_t total = rows * (cols / 8);
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(bf16_to_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, (unsigned short*)y, rows, (int)(cols / 8), ldx, ldy);
+  MI355_CHECK_LAUNCH("bf16_to_f16");
+  return MI355_OK;
+}

@@ -38,6 +38,7 @@ struct GemmParams {
   int64_t gate_rows;
   mi355_rowmap a_map, o_map;
   int act;
+  int f16_begin, f16_end;  // output columns stored as half
   // block-scaled variant
   int64_t sa_sm, sa_sk, sb_sk, sb_sn;
 };
@@ -74,6 +75,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) {
         const int i = 2 * ip + i2;
+        // wave-uniform: the half-format column range is 32-aligned
+        const int nblk = n0 + wn * TN * 32 + i * 32;
+        const bool as_f16 = nblk >= p.f16_begin && nblk < p.f16_end;
         unsigned int pk[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -94,8 +98,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             if (p.act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
             y[e] = v;
           }
-          pk[g][0] = pack_bf2(y[0], y[1]);
-          pk[g][1] = pack_bf2(y[2], y[3]);
+          if (as_f16) {
+            pk[g][0] = pack_bf2_as_f16(y[0], y[1]);
+            pk[g][1] = pack_bf2_as_f16(y[2], y[3]);
+          } else {
+            pk[g][0] = pack_bf2(y[0], y[1]);
+            pk[g][1] = pack_bf2(y[2], y[3]);
+          }
         }
         // widen: lanes l and l+32 exchange so each owns 8 consecutive channels
 #pragma unroll
@@ -493,6 +502,12 @@ int check_common(const mi355_linear_args* a, const char* who) {
   if (a->gate) MI355_REQUIRE(a->gate_rows > 0, "%s: gate_rows must be positive", who);
   MI355_REQUIRE(a->act == MI355_ACT_NONE || a->act == MI355_ACT_GELU_TANH, "%s: unknown act %d",
                 who, a->act);
+  MI355_REQUIRE(a->f16_begin % 32 == 0 && a->f16_end % 32 == 0 && a->f16_begin >= 0 &&
+                    a->f16_end >= a->f16_begin && a->f16_end <= a->N,
+                "%s: f16 column range must be 32-aligned and inside [0, N]", who);
+  MI355_REQUIRE(a->f16_begin == a->f16_end || (!a->gate && (a->fp8 || a->M > 16)),
+                "%s: f16 output columns are not available with gate/residual or on the small-M path",
+                who);
   return MI355_OK;
 }
 
@@ -561,6 +576,8 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
   p.a_map = a->a_map;
   p.o_map = a->o_map;
   p.act = a->act;
+  p.f16_begin = (int)a->f16_begin;
+  p.f16_end = (int)a->f16_end;
   p.sa_sm = p.sa_sk = p.sb_sk = p.sb_sn = 0;
   // Tile choice: 256x256 (8 waves) when the grid still covers the chip, else 128x128.
   const int64_t big_tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);

@@ -270,7 +270,7 @@ def _fwd(q, k, v, k_new, v_new, q_v, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens
         (B, Sq, H, d), (Sq * out.stride(0), out.stride(0), out.stride(1), 1))
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     if B and Sq:
-        _C.flash_attn_fwd(q4, k4, v4, o4, lse, softmax_scale, False)
+        _C.attention(q4, k4, v4, o4, lse, softmax_scale)
     if packed:  # FA3's packed layout of the log-sum-exp is [H, T]
         lse = lse.permute(1, 0, 2).reshape(H, B * Sq)
     empty = torch.empty(0, dtype=torch.float32, device=q.device)

@@ -50,6 +50,8 @@ class LinearArgs(ctypes.Structure):
         ("o_map", RowMap),
         ("fp8", _int),
         ("act", _int),
+        ("f16_begin", _i64),
+        ("f16_end", _i64),
     ]
 
 
@@ -74,6 +76,8 @@ SIGNATURES = {
     "mi355_linear_bf16": (_int, [_ptr, _ptr, _ptr, _ptr] + [_i64] * 6 + [_int, _ptr]),
     "mi355_linear_ex": (_int, [ctypes.POINTER(LinearArgs), _ptr]),
     "mi355_flash_attn_fwd": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
+    "mi355_flash_attn_fwd_f16v": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
+    "mi355_bf16_to_f16": (_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
     "mi355_rmsnorm": (_int, [_ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _i64, _f32, _ptr]),
     "mi355_fused_add_rmsnorm": (_int, [_ptr, _ptr, _ptr, _int, _i64, _i64, _f32, _ptr]),
     "mi355_qk_norm_rope": (
@@ -219,7 +223,7 @@ def linear_bf16(x, w, bias, out, act: int = 0) -> None:
 
 def linear_ex(
     a, w, out, *, M, N, K, lda, ldw, ldo, sa=None, sb=None, bias=None, residual=None, gate=None,
-    ldg=0, gate_rows=0, a_map=None, o_map=None, fp8=False, act=0,
+    ldg=0, gate_rows=0, a_map=None, o_map=None, fp8=False, act=0, f16_cols=None,
 ) -> None:
     args = LinearArgs()
     args.a, args.w, args.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -232,19 +236,24 @@ def linear_ex(
     args.o_map = _rowmap(o_map) or RowMap(0, 0, 0)
     args.fp8 = int(bool(fp8))
     args.act = int(act)
+    args.f16_begin, args.f16_end = (f16_cols if f16_cols else (0, 0))
     _check(load_library().mi355_linear_ex(ctypes.byref(args), _stream(a)), "linear_ex")
 
 
 # ----------------------------------------------------------------- attention --
-def flash_attn_fwd(q, k, v, out, lse, softmax_scale: float, causal: bool = False) -> None:
-    """q [B,Sq,H,D], k/v [B,Sk,Hk,D], out [B,Sq,H,D] (last dim contiguous)."""
+def flash_attn_fwd(q, k, v, out, lse, softmax_scale: float, causal: bool = False,
+                   v_is_f16: bool = False) -> None:
+    """q [B,Sq,H,D], k/v [B,Sk,Hk,D], out [B,Sq,H,D] (last dim contiguous).  With v_is_f16 the
+    16-bit words of `v` hold IEEE half values and P.V runs in half (more accurate)."""
     B, Sq, H, D = q.shape
     Sk, Hk = k.shape[1], k.shape[2]
     for t in (q, k, v, out):
         if t.stride(-1) != 1:
             raise RuntimeError("flash_attn_fwd: last dimension must be contiguous")
+    lib = load_library()
+    fn = lib.mi355_flash_attn_fwd_f16v if v_is_f16 else lib.mi355_flash_attn_fwd
     _check(
-        load_library().mi355_flash_attn_fwd(
+        fn(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _p(lse),
             B, Sq, Sk, H, Hk, D,
             q.stride(0), q.stride(1), q.stride(2),
@@ -255,6 +264,34 @@ def flash_attn_fwd(q, k, v, out, lse, softmax_scale: float, causal: bool = False
         ),
         "flash_attn_fwd",
     )
+
+
+def bf16_to_f16(x: torch.Tensor, y: torch.Tensor) -> None:
+    """x, y: 2-D views [rows, cols] with contiguous last dimension; y receives half bits."""
+    rows, cols = x.shape
+    _check(
+        load_library().mi355_bf16_to_f16(
+            x.data_ptr(), y.data_ptr(), rows, cols, x.stride(0), y.stride(0), _stream(x)
+        ),
+        "bf16_to_f16",
+    )
+
+
+def value_to_f16(v: torch.Tensor) -> torch.Tensor:
+    """bf16 V [B,Sk,Hk,D] (any view with D contiguous) -> a contiguous tensor of the same shape
+    whose 16-bit words are IEEE half: the V operand of flash_attn_fwd(..., v_is_f16=True)."""
+    B, Sk, Hk, D = v.shape
+    if not (v.stride(3) == 1 and v.stride(2) == D and v.stride(0) == Sk * v.stride(1)):
+        v = v.contiguous()
+    out = torch.empty((B, Sk, Hk, D), dtype=torch.float16, device=v.device)
+    if v.numel():
+        bf16_to_f16(v.as_strided((B * Sk, Hk * D), (v.stride(1), 1)), out.view(B * Sk, Hk * D))
+    return out
+
+
+def attention(q, k, v, out, lse, softmax_scale: float) -> None:
+    """Dense attention on bf16 q, k, v with the half-precision P.V product."""
+    flash_attn_fwd(q, k, value_to_f16(v), out, lse, softmax_scale, False, v_is_f16=True)
 
 
 # --------------------------------------------------------------- norm / rope --

@@ -157,7 +157,7 @@ class Mi355AttentionImpl(AttentionImpl):
             out = torch.empty((B, S, H, D), dtype=query.dtype, device=query.device)
         lse = (torch.empty((B, H, S), dtype=torch.float32, device=query.device)
                if return_softmax_lse else None)
-        _C.flash_attn_fwd(query, key, value, out, lse, self.softmax_scale, False)
+        _C.attention(query, key, value, out, lse, self.softmax_scale)
         return (out, lse) if return_softmax_lse else out
 
 

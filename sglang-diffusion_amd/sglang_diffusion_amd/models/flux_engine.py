@@ -157,7 +157,7 @@ class FluxEngine:
 
     # ---------------------------------------------------------------------- helpers --
     def _lin(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
-             gate=None, gate_rows=0, act=0, ldo=None, lda=None):
+             gate=None, gate_rows=0, act=0, ldo=None, lda=None, f16_cols=None):
         # same tile rule as csrc/gemm.hip: the 256x256 kernel when it yields >= 192 tiles
         big = ((M + 255) // 256) * ((pk.N + 255) // 256) >= 192
         self._run(("gemm_fp8" if pk.fp8 else "gemm_bf16") + ("_256" if big else "_128"),
@@ -166,7 +166,8 @@ class FluxEngine:
                   _C.linear_ex, a, pk.w, out, M=M, N=pk.N, K=pk.K, lda=lda or a.stride(0),
                   ldw=pk.w.stride(0), ldo=ldo or out.stride(0), sa=sa, sb=pk.s, bias=pk.b,
                   residual=residual, gate=gate, ldg=gate.stride(0) if gate is not None else 0,
-                  gate_rows=gate_rows, a_map=a_map, o_map=o_map, fp8=pk.fp8, act=act)
+                  gate_rows=gate_rows, a_map=a_map, o_map=o_map, fp8=pk.fp8, act=act,
+                  f16_cols=f16_cols)
 
     def _lin_mod(self, mod, a, out, *, M, o_map=None, residual=None, gate=None, gate_rows=0, act=0):
         """Unquantised nn.Linear-style module (FF, embedders)."""
@@ -221,6 +222,9 @@ class FluxEngine:
         attn = ws["attn"]
         attn4 = attn.view(B, S, H, dh)
         scale = dh ** -0.5
+        # the V third of every fused q|k|v projection is written in half format: the attention
+        # kernel multiplies half probabilities with half values
+        vcols = (2 * D, 3 * D)
 
         def norm_in(pk_fp8, shift, scl, T, rmap, M):
             """LayerNorm + modulation (+ fp8 quant) of one stream -> (activation, scales)."""
@@ -238,11 +242,11 @@ class FluxEngine:
             for (pk, off, T, rmap, M) in ((blk["qkv"], oi, Ti, map_i, Mi),
                                           (blk["add_qkv"], ot, Tt, map_t, Mt)):
                 a, sa = norm_in(pk.fp8, chunk(off, 0), chunk(off, 1), T, rmap, M)
-                self._lin(pk, a, qkv, M=M, sa=sa, o_map=rmap)
+                self._lin(pk, a, qkv, M=M, sa=sa, o_map=rmap, f16_cols=vcols)
             self._run("elementwise", 0.0, 8.0 * Ms * D, _C.qk_norm_rope, q, k, blk["naq"],
                       blk["nak"], blk["nq"], blk["nk"], Tt, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
-                      attn4, None, scale, False)
+                      attn4, None, scale, False, True)
             if blk["to_out"].fp8:
                 self._run("elementwise", 0.0, 3.0 * Ms * D, _C.per_token_quant_fp8, attn, ws["aq"],
                           ws["as_"])
@@ -271,12 +275,12 @@ class FluxEngine:
         for i, blk in enumerate(self.sgl):
             off = self.mod_off[("s", i)]
             a, sa = norm_in(blk["qkv"].fp8, chunk(off, 0), chunk(off, 1), S, None, Ms)
-            self._lin(blk["qkv"], a, qkv, M=Ms, sa=sa)
+            self._lin(blk["qkv"], a, qkv, M=Ms, sa=sa, f16_cols=vcols)
             self._lin(blk["mlp"], a, mlp_cols, M=Ms, sa=sa, act=1, ldo=catw)
             self._run("elementwise", 0.0, 8.0 * Ms * D, _C.qk_norm_rope, q, k, blk["nq"], blk["nk"],
                       blk["nq"], blk["nk"], 0, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
-                      attn_in_cat, None, scale, False)
+                      attn_in_cat, None, scale, False, True)
             if blk["out"].fp8:
                 self._run("elementwise", 0.0, 3.0 * Ms * catw, _C.per_token_quant_fp8, cat,
                           ws["cq"], ws["cs"])

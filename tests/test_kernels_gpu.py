@@ -242,6 +242,71 @@ def test_flash_attention_strided_views(device):
     assert wide[:, :, H * D:].abs().sum().item() == 0
 
 
+def _f16_bits_to_float(t):
+    return t.cpu().view(torch.float16).float()
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D", [(2, 333, 333, 3, 3, 128), (1, 200, 77, 4, 2, 64),
+                                             (1, 640, 640, 24, 24, 128)])
+def test_flash_attention_half_pv_vs_oracle(device, B, Sq, Sk, H, Hk, D):
+    """P and V in IEEE half: about 1/3 of the bf16-P form's distance to the fp32-softmax oracle
+    (what is left is mostly the bf16 rounding of the output, which the oracle shares)."""
+    q = torch.randn(B, Sq, H, D, generator=g(41)).bfloat16()
+    k = torch.randn(B, Sk, Hk, D, generator=g(42)).bfloat16()
+    v = torch.randn(B, Sk, Hk, D, generator=g(43)).bfloat16()
+    ref, lse_ref = ops.attention(q, k, v, return_lse=True)
+    out = torch.empty(B, Sq, H, D, dtype=torch.bfloat16, device=device)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=device)
+    _C.attention(q.to(device), k.to(device), v.to(device), out, lse, D ** -0.5)
+    assert rel_l2(out, ref) <= 1e-3
+    assert (lse.cpu() - lse_ref).abs().max() <= 1e-4
+    out_bf = torch.empty_like(out)
+    _C.flash_attn_fwd(q.to(device), k.to(device), v.to(device), out_bf, None, D ** -0.5)
+    assert rel_l2(out, ref) < rel_l2(out_bf, ref)
+
+
+def test_bf16_to_f16_exact_and_saturating(device):
+    x = torch.randn(37, 256, generator=g(48)).bfloat16()
+    x[0, :4] = torch.tensor([1e6, -1e6, 65280.0, 0.0]).bfloat16()
+    wide = torch.zeros(37, 512, dtype=torch.bfloat16)
+    wide[:, 128:384] = x
+    y = torch.empty(37, 256, dtype=torch.float16, device=device)
+    _C.bf16_to_f16(wide.to(device)[:, 128:384], y)
+    exp = x.float().clamp(-65504, 65504).half()
+    assert torch.equal(y.cpu(), exp)
+    v = torch.randn(2, 9, 3, 128, generator=g(49)).bfloat16()
+    big = torch.randn(2, 9, 3, 3, 128, generator=g(50)).bfloat16()
+    assert torch.equal(_C.value_to_f16(v.to(device)).cpu(), v.half())
+    assert torch.equal(_C.value_to_f16(big.to(device)[:, :, 2]).cpu(), big[:, :, 2].half())
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_linear_ex_half_output_columns(device, fp8):
+    """Columns [256, 384) of the result come out in half format holding the SAME bf16 values."""
+    M, N, K = 300, 384, 256
+    x = torch.randn(M, K, generator=g(51)).bfloat16()
+    w = (torch.randn(N, K, generator=g(52)) * K ** -0.5).bfloat16()
+    b = (torch.randn(N, generator=g(53)) * 0.1).bfloat16()
+    kw = {}
+    if fp8:
+        xq, xs = ops.per_token_quant_fp8(x)
+        wq, ws = ops.quantize_weight_per_channel(w)
+        a_d, w_d = xq.to(device), wq.to(device)
+        kw = dict(sa=xs.view(-1).to(device), sb=ws.to(device), fp8=True)
+    else:
+        a_d, w_d = x.to(device), w.to(device)
+    plain = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+    mixed = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+    _C.linear_ex(a_d, w_d, plain, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, bias=b.to(device), **kw)
+    _C.linear_ex(a_d, w_d, mixed, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, bias=b.to(device),
+                 f16_cols=(256, 384), **kw)
+    assert torch.equal(mixed[:, :256].cpu(), plain[:, :256].cpu())
+    as_half = _f16_bits_to_float(mixed[:, 256:].contiguous())
+    assert torch.equal(as_half, plain[:, 256:].float().cpu())
+    with pytest.raises(RuntimeError):
+        _C.linear_ex(a_d, w_d, mixed, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, f16_cols=(250, 384), **kw)
+
+
 # ------------------------------------------------------------------------- norm / rope --
 @pytest.mark.parametrize("rows,dim,wf32", [(37, 128, True), (5, 3072, False), (1000, 128, True)])
 def test_rmsnorm_vs_oracle(device, rows, dim, wf32):
