@@ -218,6 +218,19 @@ def main():
                 "launches_per_step": d["n"] // nsteps_traced,
                 "avg_launch_us": d["ms"] * 1e3 / d["n"],
                 "flop_per_launch": d["flops"] / d["n"]}
+    # HBM-side bytes per launch of that kernel come from separate rocprofv3 --pmc passes over
+    # this same command (a running process cannot read them); the newest summary is reported
+    try:
+        import glob
+
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        key = "gemm_kernel<1, 4, 2, 2, 4, false>" if args.mode == "fp8" else "gemm_kernel<0, 4, 2, 2, 4, false>"
+        roofline["traffic"] = json.load(open(pmc))["kernels"][key]["traffic_bytes_per_launch"]
+        roofline["traffic_unit"] = "bytes per launch at the L2 memory side (2*FETCH_SIZE + WRITE_SIZE)"
+        roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
+        roofline["algorithmic_bytes_per_launch"] = d["bytes"] / d["n"]
+    except Exception:
+        roofline["traffic"] = None
     fl = flux_step_flops(B, n_double=cfg.num_layers, n_single=cfg.num_single_layers)
 
     if rank != 0:
