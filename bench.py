@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="requests per GPU")
     ap.add_argument("--mode", default="fp8", choices=["fp8", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--schnell", action="store_true",
+                    help="Flux.1-schnell: no guidance embedder, bf16, batch 1, 4-step schedule "
+                         "(a parity-test configuration; the result is NOT the metric)")
     ap.add_argument("--layers", type=int, nargs=2, default=None,
                     help="(debug) override #double #single blocks; the result is then NOT the metric")
     args = ap.parse_args()
@@ -137,6 +140,12 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = flux_dev_config()
+    global NUM_INFERENCE_STEPS
+    if args.schnell:
+        from sglang_diffusion_amd.models.flux import flux_schnell_config
+
+        cfg = flux_schnell_config()
+        args.mode, args.batch, NUM_INFERENCE_STEPS = "bf16", 1, 4
     if args.layers:
         cfg.num_layers, cfg.num_single_layers = args.layers
     qc = Fp8Config(is_checkpoint_fp8_serialized=False) if args.mode == "fp8" else None
@@ -148,7 +157,7 @@ def main():
     B = args.batch
     req = make_synthetic_request(B, 1024, 1024, NUM_INFERENCE_STEPS, device=dev, seed=rank)
     timesteps = stage.prepare_timesteps(req, dev)
-    guidance = stage._build_guidance(B, dev, req.embedded_cfg_scale)
+    guidance = stage._build_guidance(B, dev, req.embedded_cfg_scale) if cfg.guidance_embeds else None
     freqs = stage._freqs_cis(req.prompt_embeds.shape[1], req.width, req.height, dev)
     ts_host = stage.scheduler._timesteps_host
     latents = req.latents
@@ -244,15 +253,17 @@ def main():
         except Exception as e:  # the baseline is informational; never lose the GPU line
             cpu = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
                    "sample": f"failed: {type(e).__name__}: {e}"}
-    is_metric_config = args.layers is None and args.mode == "fp8" and B == 4
+    is_metric_config = args.layers is None and args.mode == "fp8" and B == 4 and not args.schnell
     out = {
-        "metric": "images_per_sec_flux1dev_1024x1024_50step_fp8",
+        "metric": ("images_per_sec_flux1schnell_1024x1024_4step_bf16" if args.schnell
+                   else "images_per_sec_flux1dev_1024x1024_50step_fp8"),
         "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp8_e4m3 (W8A8 attention/single-block linears) + bf16 (FF, attention)",
+        "dtype": ("fp8_e4m3 (W8A8 attention/single-block linears) + bf16 (FF, attention)"
+                  if args.mode == "fp8" else "bf16"),
         "data": "synthetic",
-        "config": {"workload": ("Flux.1-dev DiT, 1024x1024 (4096 image + 512 text tokens), "
+        "config": {"workload": (("Flux.1-schnell" if args.schnell else "Flux.1-dev") + " DiT, 1024x1024 (4096 image + 512 text tokens), "
                                 f"{NUM_INFERENCE_STEPS}-step schedule, batch {B} per GPU, "
                                 f"{args.mode}" + ("" if is_metric_config else " [NOT the metric config]")),
                    "global_batch": world * B, "seq_len": 4608, "parallelism": f"dp{world}",
