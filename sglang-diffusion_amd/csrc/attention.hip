@@ -91,37 +91,55 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
 
   // ---- LDS-DMA sources: piece = 1 KiB = 1024/ROWB rows; [K tile | V tile] ----
-  const unsigned short* kbase = p.k + b * p.k_sb + hk * p.k_sh;
-  const unsigned short* vbase = p.v + b * p.v_sb + hk * p.v_sh;
-  constexpr int ROWS_PER_PIECE = 1024 / ROWB;  // 4 (D=128) or 8 (D=64)
-  // per piece: which tile (K or V), row in tile, logical chunk for this lane
+  // A full tile is fetched as (wave-uniform tile base) + (loop-invariant 32-bit lane offset):
+  // no per-lane address arithmetic inside the loop.  Only the last, partial tile clamps rows.
+  const unsigned char* kbase =
+      reinterpret_cast<const unsigned char*>(p.k + b * p.k_sb + hk * p.k_sh);
+  const unsigned char* vbase =
+      reinterpret_cast<const unsigned char*>(p.v + b * p.v_sb + hk * p.v_sh);
+  static_assert(PIECES % 2 == 0, "first half of a wave's pieces is K, second half V");
   int prow[PIECES];
   int pchunk[PIECES];
-  bool pisv[PIECES];
+  unsigned int voff[PIECES];
 #pragma unroll
   for (int i = 0; i < PIECES; ++i) {
     const int piece = wave + 4 * i;             // 0 .. 2*TILE_BYTES/1024-1
     const int lin = piece * 64 + lane;          // 16-B slot index in [K|V] stage image
     const int slot = lin % (TILE_BYTES / 16);   // slot within its tile
-    pisv[i] = lin >= TILE_BYTES / 16;
+    const bool isv = i >= PIECES / 2;           // == (lin >= TILE_BYTES / 16)
     const int row = slot / CPR;
     const int pc = slot % CPR;
     prow[i] = row;
-    pchunk[i] = pisv[i] ? (pc ^ (v_swz(row) & (CPR - 1))) : (pc ^ (k_swz(row) & (CPR - 1)));
+    pchunk[i] = isv ? (pc ^ (v_swz(row) & (CPR - 1))) : (pc ^ (k_swz(row) & (CPR - 1)));
+    voff[i] = (unsigned int)(row * (isv ? p.v_ss : p.k_ss) * 2 + pchunk[i] * 16);
   }
-  (void)ROWS_PER_PIECE;
+  const int64_t k_tile_step = (int64_t)KV * p.k_ss * 2, v_tile_step = (int64_t)KV * p.v_ss * 2;
 
   auto stage = [&](int buf, int k0) {
+    if (k0 + KV <= p.Sk) {
+      const unsigned char* kt0 = kbase + (int64_t)(k0 / KV) * k_tile_step;  // wave-uniform
+      const unsigned char* vt0 = vbase + (int64_t)(k0 / KV) * v_tile_step;
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-      const int piece = wave + 4 * i;
-      int key = k0 + prow[i];
-      if (key >= p.Sk) key = p.Sk - 1;
-      const unsigned short* src = pisv[i] ? vbase + (int64_t)key * p.v_ss + pchunk[i] * 8
-                                          : kbase + (int64_t)key * p.k_ss + pchunk[i] * 8;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
-                                       (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16, 0,
-                                       0);
+      for (int i = 0; i < PIECES; ++i) {
+        const int piece = wave + 4 * i;
+        const unsigned char* src = (i >= PIECES / 2 ? vt0 : kt0) + voff[i];
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
+                                         (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16,
+                                         0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const int piece = wave + 4 * i;
+        int key = k0 + prow[i];
+        if (key >= p.Sk) key = p.Sk - 1;
+        const unsigned char* src = i >= PIECES / 2
+                                       ? vbase + ((int64_t)key * p.v_ss * 2 + pchunk[i] * 16)
+                                       : kbase + ((int64_t)key * p.k_ss * 2 + pchunk[i] * 16);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
+                                         (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16,
+                                         0, 0);
+      }
     }
   };
 
@@ -137,7 +155,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   // second read) so that element j of this lane is key 16st + 8(j>>2) + 4hh + (j&3),
   // the order in which the S^T accumulator registers hold P.
   const int li = lane & 15, qq = li >> 2, pp = li & 3, g2 = (lane >> 4) & 1;
-  // byte offset inside a V tile for (key row, dv block dvb) computed at use.
+  // Loop-invariant lane part of the V read address, per dv block and per 8-key half: the
+  // swizzle term v_swz(key) only sees key bits 0..3 = (half, hh, qq), so the (kb, st) part of
+  // the key is a plain constant that goes into the instruction's immediate offset.
+  int vlane[DVB][2];
+#pragma unroll
+  for (int d = 0; d < DVB; ++d)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int key = half * 8 + 4 * hh + qq;
+      const int col = d * 32 + g2 * 16 + 4 * pp;
+      vlane[d][half] =
+          key * ROWB + ((((col >> 3) ^ (v_swz(key) & (CPR - 1)))) << 4) + ((col & 7) << 1);
+    }
 
   f32x16 oacc[DVB];
 #pragma unroll
@@ -150,8 +180,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 
   const int ntiles = (p.Sk + KV - 1) / KV;
   stage(0, 0);
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
+  // One KV tile out of LDS buffer BUF (compile time, so every LDS address below is a
+  // loop-invariant lane offset plus an immediate).
+  auto tile_body = [&](auto bufc, int t) {
+    constexpr int cur = decltype(bufc)::value;
     const int k0 = t * KV;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -188,10 +220,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
+    // Lazy running max: the reference point of the exponentials only has to be NEAR the row
+    // maximum.  It moves (and O, l are rescaled) only when some row of the wave has outgrown
+    // it by more than 2^LAZY_LOG2 in the exponent; until then p = 2^((s - m) c) may reach
+    // 2^LAZY_LOG2 instead of 1, which fp32 sums and half / bf16 probabilities hold easily.
+    // The softmax value is unchanged (numerator and denominator share the reference).
+    constexpr float LAZY_LOG2 = 8.0f;
+    const bool outgrown = (mx - m_run) * c > LAZY_LOG2;  // true on the first tile (m_run = -inf)
+    if (__builtin_amdgcn_ballot_w64(outgrown) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DVB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    }
+    const float mc = m_run * c;
     float rs = 0.f;
     typedef typename std::conditional<F16, f16x8, bf16x8>::type pfrag_t;
     pfrag_t pf[2][2];
@@ -214,11 +260,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
           }
         }
     }
-    l_run = l_run * alpha + rs;
-#pragma unroll
-    for (int d = 0; d < DVB; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    l_run += rs;
 
     // ---- O^T += V^T P^T ---------------------------------------------------------
 #pragma unroll
@@ -228,15 +270,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int d = 0; d < DVB; ++d) {
           if constexpr (TRREAD) {
-            int off[2];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-              const int key = kb * 32 + st * 16 + half * 8 + 4 * hh + qq;  // row this lane addresses
-              const int col = d * 32 + g2 * 16 + 4 * pp;                    // first of 4 columns
-              const int ch = col >> 3;
-              off[half] =
-                  key * ROWB + (((ch ^ (v_swz(key) & (CPR - 1)))) << 4) + ((col & 7) << 1);
-            }
+            const int off[2] = {vlane[d][0] + (kb * 32 + st * 16) * ROWB,
+                                vlane[d][1] + (kb * 32 + st * 16) * ROWB};
             if constexpr (F16) {
               const f16x4 t0 = __builtin_bit_cast(
                   f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
@@ -268,6 +303,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][st], oacc[d], 0, 0, 0);
           }
         }
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile_body(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile_body(std::integral_constant<int, 1>{}, t + 1);
   }
 
   // ---- finish: combine the two half-row sums, normalise, store -------------------
@@ -342,7 +381,8 @@ static int attn_entry(const void* q, const void* k, const void* v, void* out, fl
   MI355_REQUIRE(B >= 0 && Sq >= 0 && Sk >= 0 && H > 0 && Hk > 0 && H % Hk == 0,
                 "flash_attn_fwd: bad shape B=%ld Sq=%ld Sk=%ld H=%ld Hk=%ld", (long)B, (long)Sq,
                 (long)Sk, (long)H, (long)Hk);
-  MI355_REQUIRE(Sq < (1ll << 31) && Sk < (1ll << 31) && H < 65536 && B < 65536,
+  MI355_REQUIRE(Sq < (1ll << 31) && Sk < (1ll << 31) && H < 65536 && B < 65536 &&
+                    k_ss < (1ll << 24) && v_ss < (1ll << 24),
                 "flash_attn_fwd: dimension too large");
   const int64_t strides[] = {q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh};
   for (int64_t s : strides)

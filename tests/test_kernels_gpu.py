@@ -229,6 +229,30 @@ def test_flash_attention_online_softmax_rescale(device):
     assert rel_l2(out[0, 17], ref[0, 17]) <= 1e-2
 
 
+def test_flash_attention_lazy_max_on_growing_scores(device):
+    """Scores that climb steadily along the key axis: the running reference max lags behind
+    the true max between rescales (probabilities above 1 in the meantime) and is moved
+    several times; both P.V precisions must still match the oracle."""
+    B, S, H, D = 1, 1024, 2, 128
+    q = torch.randn(B, S, H, D, generator=g(81)).bfloat16()
+    k = torch.randn(B, S, H, D, generator=g(82)).bfloat16() * 0.3
+    v = torch.randn(B, S, H, D, generator=g(83)).bfloat16()
+    # add a component along q's mean direction that grows with the key index: scaled scores
+    # rise by roughly 40 (58 in log2 units) from the first to the last key
+    u = q.float().mean(dim=1, keepdim=True)
+    u = u / u.norm(dim=-1, keepdim=True)
+    ramp = torch.linspace(0, 1, S).view(1, S, 1, 1)
+    k = (k.float() + ramp * u * 40.0).bfloat16()
+    ref, lse_ref = ops.attention(q, k, v, return_lse=True)
+    for fn, tol in ((_C.flash_attn_fwd, 4e-3), (_C.attention, 1.5e-3)):
+        out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=device)
+        lse = torch.empty(B, H, S, dtype=torch.float32, device=device)
+        fn(q.to(device), k.to(device), v.to(device), out, lse, D ** -0.5)
+        assert torch.isfinite(out.float()).all()
+        assert rel_l2(out, ref) <= tol
+        assert (lse.cpu() - lse_ref).abs().max() <= 2e-3
+
+
 def test_flash_attention_strided_views(device):
     """q/k/v as slices of a fused [B,S,3,H,D] buffer, output into a wider row."""
     B, S, H, D = 2, 130, 4, 128
