@@ -130,13 +130,16 @@ def main():
     from sglang_diffusion_amd.runtime.synthetic import (init_synthetic_weights,
                                                         make_synthetic_request)
 
-    rank, world, local = init_distributed("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1
+    # RCCL ("nccl") between the ranks of one node; MI355_BENCH_BACKEND=gloo lets several ranks
+    # share one GPU for a rehearsal of the multi-rank control flow
+    backend = os.environ.get("MI355_BENCH_BACKEND", "nccl")
+    rank, world, local = init_distributed(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1
                                           else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     cfg = flux_dev_config()
@@ -268,8 +271,8 @@ def main():
                                 f"{args.mode}" + ("" if is_metric_config else " [NOT the metric config]")),
                    "global_batch": world * B, "seq_len": 4608, "parallelism": f"dp{world}",
                    "num_double_blocks": cfg.num_layers, "num_single_blocks": cfg.num_single_layers},
-        "step_tflops_total": fl["total"] / step_s / 1e12,
-        "mfma_utilisation_vs_fp8_peak": fl["total"] / step_s / 1e12 / PEAK_FP8_TFLOPS,
+        "step_tflops_total": world * fl["total"] / step_s / 1e12,  # whole job
+        "mfma_utilisation_vs_fp8_peak": fl["total"] / step_s / 1e12 / PEAK_FP8_TFLOPS,  # per GPU
         "mixed_roofline_min_ms": (fl["fp8"] / (PEAK_FP8_TFLOPS * 1e12)
                                   + (fl["bf16"] + fl["attn"]) / (PEAK_BF16_TFLOPS * 1e12)) * 1e3,
         "roofline": roofline, "breakdown": breakdown, "cpu_baseline": cpu,

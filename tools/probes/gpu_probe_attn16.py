@@ -1,6 +1,6 @@
 """Accuracy and speed of the two attention forms against an fp32 softmax reference."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sglang-diffusion_amd"))
 import torch
 from sglang_diffusion_amd import _C
