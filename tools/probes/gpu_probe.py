@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sglang-diffusion_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "sglang-diffusion_amd"))
 from sglang_diffusion_amd import _C  # noqa: E402
 
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Second probe: fp8 conversion corner cases and ds_read_b64_tr_b16 semantics."""
 import os, sys, subprocess, ctypes
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sglang-diffusion_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "sglang-diffusion_amd"))
 from sglang_diffusion_amd import _C
 dev = torch.device("cuda:0")
 

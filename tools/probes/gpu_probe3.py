@@ -1,6 +1,6 @@
 import os, sys
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "sglang-diffusion_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "sglang-diffusion_amd"))
 from sglang_diffusion_amd import _C
 dev = torch.device("cuda:0")
 torch.set_printoptions(linewidth=200, precision=3, sci_mode=False)
