@@ -192,15 +192,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const unsigned char* vt = kt + TILE_BYTES;
 
     // ---- S^T = K Q^T : two 32-key blocks ------------------------------------
+    // The two 32-key chains are interleaved and every K fragment is read one step before the
+    // MFMA that consumes it, so neither the LDS latency nor the accumulator dependency of a
+    // chain is exposed.
     f32x16 sacc[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+    {
+      bf16x8 kf[2][2];  // [parity of step][kb]
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        kf[0][kb] = *reinterpret_cast<const bf16x8*>(kt + kb * 32 * ROWB + koff[0]);
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + kb * 32 * ROWB + koff[s]);
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+        if (s + 1 < KSTEPS) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+            kf[(s + 1) & 1][kb] =
+                *reinterpret_cast<const bf16x8*>(kt + kb * 32 * ROWB + koff[s + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads of step s+1 ahead of step s's MFMAs
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s & 1][kb], qf[s], sacc[kb], 0, 0, 0);
       }
     }
     // mask keys past the end (last tile only; wave-uniform branch)
