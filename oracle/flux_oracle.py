@@ -30,10 +30,14 @@ from . import ops
 class FluxOracle:
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, num_layers: int,
                  num_single_layers: int, num_heads: int, head_dim: int, guidance_embeds: bool,
-                 fp8: bool = False, axes_dims_rope=(16, 56, 56), rope_bf16_cos_sin: bool = False):
+                 fp8: bool = False, axes_dims_rope=(16, 56, 56), rope_bf16_cos_sin: bool = False,
+                 fp8_block: bool = False):
         """state_dict holds bf16 weights (reference names).  fp8=True quantises the linears the
         reference builds with quant_config (attention projections, single-block proj_mlp /
-        proj_out) per output channel at load time (layers/quantization/fp8.py:357-364)."""
+        proj_out) per output channel at load time (layers/quantization/fp8.py:357-364).
+        fp8_block=True instead takes them through the offline 128x128 block quantiser
+        (tools/convert_hf_to_fp8.py:48-79) and the block linear (fp8_utils.py:518-548), the
+        format of an fp8-serialised checkpoint."""
         self.sd = {k: v.detach().cpu() for k, v in state_dict.items()}
         self.L, self.LS, self.H, self.dh = num_layers, num_single_layers, num_heads, head_dim
         self.D = num_heads * head_dim
@@ -42,10 +46,12 @@ class FluxOracle:
         self.axes = tuple(axes_dims_rope)
         self.rope_bf16 = rope_bf16_cos_sin
         self.q: Dict[str, tuple] = {}
-        if fp8:
+        self.fp8_block = fp8_block
+        if fp8 or fp8_block:
             for k, w in self.sd.items():
                 if k.endswith(".weight") and self._is_fp8_layer(k[:-7]):
-                    self.q[k[:-7]] = ops.quantize_weight_per_channel(w)
+                    self.q[k[:-7]] = (ops.quantize_weight_block(w) if fp8_block
+                                      else ops.quantize_weight_per_channel(w))
 
     @staticmethod
     def _is_fp8_layer(name: str) -> bool:
@@ -61,7 +67,7 @@ class FluxOracle:
         b = self.sd.get(name + ".bias")
         if name in self.q:
             wq, ws = self.q[name]
-            y = ops.fp8_linear(x, wq, ws, b)
+            y = ops.fp8_block_linear(x, wq, ws, b) if self.fp8_block else ops.fp8_linear(x, wq, ws, b)
         else:
             y = F.linear(x, self.sd[name + ".weight"], b)
         if act == "gelu":

@@ -36,3 +36,33 @@ def small_inputs(B, Ti, Tt, cfg, seed=0):
     t = torch.full((B,), 873.5)
     guid = torch.full((B,), 3.5).to(torch.bfloat16) * 1000.0
     return hid, enc, pooled, t, guid
+
+
+def build_small_block_fp8(device, guidance_embeds: bool = True, seed: int = 0, **over):
+    """The small DiT as an fp8-SERIALISED checkpoint with 128x128 weight blocks: bf16 weights are
+    drawn as in build_small, the quantised layers go through the offline converter's rule on
+    the host and are loaded as `weight` (fp8) + `weight_scale_inv`, like the reference's loader
+    fills them.  Returns (model, bf16 state dict, cfg)."""
+    from oracle import ops as O
+
+    cfg = FluxArchConfig(**{**SMALL, **over}, guidance_embeds=guidance_embeds)
+    plain = FluxTransformer2DModel(cfg, quant_config=None)
+    init_synthetic_weights(plain, seed=seed, host_rng=True)
+    state = {k: v.detach().clone() for k, v in plain.state_dict().items()}
+    qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="dynamic",
+                   weight_block_size=[128, 128])
+    model = FluxTransformer2DModel(cfg, quant_config=qc)
+    with torch.no_grad():
+        params = dict(model.named_parameters())
+        for name, p in params.items():
+            if name.endswith(".weight_scale_inv"):
+                continue
+            if p.dtype == torch.float8_e4m3fn:
+                q, s = O.quantize_weight_block(state[name])
+                p.data.copy_(q)
+                params[name[:-len("weight")] + "weight_scale_inv"].data.copy_(s)
+            else:
+                p.data.copy_(state[name].to(p.dtype))
+    model = model.to(device)
+    model.process_weights_after_loading()
+    return model, state, cfg

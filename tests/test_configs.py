@@ -84,3 +84,30 @@ def test_c2_schnell_four_steps_bf16_batch1(device):
     print(f"schnell-like 4 steps: rel {e:.2e}")
     # four steps of a network whose single forward sits at the 5e-3 two-implementations floor
     assert e <= 1.5e-2
+
+
+@pytest.mark.gpu
+def test_block_quantised_fp8_checkpoint_end_to_end(device):
+    """An fp8-serialised checkpoint with 128x128 weight blocks (what the reference's
+    tools/convert_hf_to_fp8.py writes) through the plugin layers: per-token-group activation
+    quantisation + block-scaled GEMM, against the oracle's restatement of the same path."""
+    from sglang_diffusion_amd.runtime.denoise import DenoisingStage
+    from tests.flux_small import build_small_block_fp8
+
+    model, state, cfg = build_small_block_fp8(device)
+    from oracle.flux_oracle import FluxOracle
+
+    orc = FluxOracle(state, num_layers=cfg.num_layers, num_single_layers=cfg.num_single_layers,
+                     num_heads=cfg.num_attention_heads, head_dim=cfg.attention_head_dim,
+                     guidance_embeds=True, fp8_block=True, axes_dims_rope=cfg.axes_dims_rope)
+    req = make_synthetic_request(2, height=128, width=96, num_inference_steps=2, device="cpu",
+                                 seed=11, text_len=24, joint_dim=cfg.joint_attention_dim,
+                                 pooled_dim=cfg.pooled_projection_dim)
+    ref = flux_oracle.denoise(orc, req.latents.clone(), req.prompt_embeds, req.pooled_embeds,
+                              height=128, width=96, num_steps=2)
+    for name in ("latents", "prompt_embeds", "pooled_embeds"):
+        setattr(req, name, getattr(req, name).to(device))
+    out = DenoisingStage(model, fused=True).forward(req).latents   # falls back to the layer path
+    e = rel_l2(out, ref)
+    print(f"block-quantised checkpoint, 2 steps: rel {e:.2e}")
+    assert e <= 2.5e-2
