@@ -135,3 +135,36 @@ def test_batch_rows_are_independent_at_flux_shapes(device):
     assert torch.isfinite(full.float()).all()
     assert torch.equal(full[1:2], one)
     assert torch.equal(permd, full[perm.to(device)])
+
+
+def test_dp_batch_scheduler_on_the_hip_path(device):
+    """The data-parallel batch scheduler (one rank here) drains a queue of requests of different
+    batch sizes, with and without true CFG, in micro-batches; every request's latents equal the
+    ones it gets when run alone (batch rows are independent, so this is exact)."""
+    from sglang_diffusion_amd.runtime.batch_scheduler import DataParallelBatchScheduler
+    from sglang_diffusion_amd.runtime.denoise import DenoisingStage
+    from sglang_diffusion_amd.runtime.synthetic import make_synthetic_request
+
+    model, state, cfg = build_small(device, fp8=True)
+
+    def req(b, seed, cfg_pair=False):
+        r = make_synthetic_request(b, height=128, width=128, num_inference_steps=3, device=device,
+                                   seed=seed, text_len=32, joint_dim=cfg.joint_attention_dim,
+                                   pooled_dim=cfg.pooled_projection_dim)
+        if cfg_pair:
+            r.guidance_scale = 3.5
+            r.negative_prompt_embeds = torch.zeros_like(r.prompt_embeds)
+            r.neg_pooled_embeds = torch.zeros_like(r.pooled_embeds)
+        return r
+
+    specs = [(1, 1, False), (2, 2, False), (1, 3, True), (1, 4, False), (1, 5, True), (1, 6, False)]
+    alone = []
+    for b, seed, pair in specs:
+        alone.append(DenoisingStage(model, fused=True).forward(req(b, seed, pair)).latents.clone())
+    sch = DataParallelBatchScheduler(DenoisingStage(model, fused=True), max_samples_per_step=4)
+    for b, seed, pair in specs:
+        sch.add_request(req(b, seed, pair))
+    outs = sch.run()
+    assert len(outs) == len(specs)
+    for got, exp in zip(outs, alone):
+        assert torch.equal(got, exp)
