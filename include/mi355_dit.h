@@ -34,6 +34,8 @@ extern "C" {
 #define MI355_ACT_GELU_TANH 1
 
 const char* mi355_last_error(void);
+/* 2: mi355_linear_args gained f16_begin/f16_end; mi355_flash_attn_fwd_f16v and
+ *    mi355_bf16_to_f16 were added. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --

@@ -363,16 +363,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 template <int D, bool TRREAD, bool F16>
 int launch_attn(const AttnParams& p, hipStream_t st) {
   constexpr int LDS = 2 * 2 * 64 * D * 2;
-  static bool attr_set = false;
+  // the LDS limit is a per-device function attribute: remember which devices have it
+  static unsigned long long attr_devices = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
   auto kfn = attn_fwd_kernel<D, TRREAD, F16>;
-  if (!attr_set) {
+  if (!(attr_devices & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mi355_set_error("flash_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MI355_EHIP;
     }
-    attr_set = true;
+    attr_devices |= dev_bit;
   }
   dim3 grid((unsigned)((p.Sq + 127) / 128), (unsigned)p.H, (unsigned)p.B), block(256);
   hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);

@@ -456,11 +456,13 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(
 
 // workgroups of one kernel that are resident at once: CUs x (workgroups per CU by LDS)
 int resident_workgroups(int lds_bytes) {
-  static int cus = 0;
+  static int cus_of[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& cus = cus_of[dev & 63];
   if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
     cus = n;
   }
@@ -472,16 +474,20 @@ template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
+  // the LDS limit is a per-device function attribute: remember which devices have it
+  static unsigned long long attr_devices = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
   auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS>;
-  if (!attr_set) {
+  if (!(attr_devices & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mi355_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MI355_EHIP;
     }
-    attr_set = true;
+    attr_devices |= dev_bit;
   }
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
