@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--schnell", action="store_true",
                     help="Flux.1-schnell: no guidance embedder, bf16, batch 1, 4-step schedule "
                          "(a parity-test configuration; the result is NOT the metric)")
+    ap.add_argument("--checkpoint", default=None,
+                    help="a diffusers `transformer/` directory (config.json + *.safetensors) to run "
+                         "instead of random-init weights; \"data\" then says so")
     ap.add_argument("--layers", type=int, nargs=2, default=None,
                     help="(debug) override #double #single blocks; the result is then NOT the metric")
     args = ap.parse_args()
@@ -152,10 +155,17 @@ def main():
     if args.layers:
         cfg.num_layers, cfg.num_single_layers = args.layers
     qc = Fp8Config(is_checkpoint_fp8_serialized=False) if args.mode == "fp8" else None
-    with torch.device(dev):
-        model = FluxTransformer2DModel(cfg, quant_config=qc)
-    init_synthetic_weights(model, seed=0, host_rng=False)
-    model.process_weights_after_loading()
+    if args.checkpoint:
+        from sglang_diffusion_amd.runtime.loader import get_component_config, load_flux_transformer
+
+        declared = "quantization_config" in get_component_config(args.checkpoint)
+        model, _ = load_flux_transformer(args.checkpoint, dev, quant_config=None if declared else qc)
+        cfg = model.config
+    else:
+        with torch.device(dev):
+            model = FluxTransformer2DModel(cfg, quant_config=qc)
+        init_synthetic_weights(model, seed=0, host_rng=False)
+        model.process_weights_after_loading()
     stage = DenoisingStage(model, fused=True)
     B = args.batch
     req = make_synthetic_request(B, 1024, 1024, NUM_INFERENCE_STEPS, device=dev, seed=rank)
@@ -265,7 +275,8 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "dtype": ("fp8_e4m3 (W8A8 attention/single-block linears) + bf16 (FF, attention)"
                   if args.mode == "fp8" else "bf16"),
-        "data": "synthetic",
+        "data": ("synthetic inputs, weights from " + os.path.basename(os.path.normpath(args.checkpoint))
+                 if args.checkpoint else "synthetic"),
         "config": {"workload": (("Flux.1-schnell" if args.schnell else "Flux.1-dev") + " DiT, 1024x1024 (4096 image + 512 text tokens), "
                                 f"{NUM_INFERENCE_STEPS}-step schedule, batch {B} per GPU, "
                                 f"{args.mode}" + ("" if is_metric_config else " [NOT the metric config]")),

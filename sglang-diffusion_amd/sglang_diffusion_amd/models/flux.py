@@ -102,9 +102,15 @@ class FluxAttention(nn.Module):
         self.added_kv_proj_dim = added_kv_proj_dim
 
         def lin(i, o, b, name):
+            # Only the two output projections carry their module path (flux.py:286,332); the
+            # q/k/v projections are built with an empty prefix (flux.py:255-276,303-325).  That
+            # matters for fp8 checkpoints: the ignore list of a converted checkpoint names the
+            # top-level "proj_out", which is matched as a SUBSTRING of a layer's prefix
+            # (srt/layers/quantization/utils.py:80), and an empty prefix never matches.
+            named = name in ("to_out.0", "to_add_out") and prefix
             return ColumnParallelLinear(i, o, bias=b, gather_output=True, params_dtype=dtype,
                                         quant_config=quant_config,
-                                        prefix=f"{prefix}.{name}" if prefix else name)
+                                        prefix=f"{prefix}.{name}" if named else "")
 
         self.norm_q = RMSNorm(dim_head, eps=eps)
         self.norm_k = RMSNorm(dim_head, eps=eps)
@@ -173,18 +179,18 @@ class FluxSingleTransformerBlock(nn.Module):
         super().__init__()
         self.mlp_hidden_dim = int(dim * mlp_ratio)
         self.norm = AdaLayerNormZeroSingle(dim, dtype=dtype)
+        # proj_mlp, proj_out and the attention of a single block are built WITHOUT a prefix
+        # (flux.py:476-503), so an ignore-list entry "proj_out" (the model's final projection)
+        # does not switch off quantisation of every single block's proj_out.
         self.proj_mlp = ColumnParallelLinear(dim, self.mlp_hidden_dim, bias=True,
                                              gather_output=True, params_dtype=dtype,
-                                             quant_config=quant_config,
-                                             prefix=f"{prefix}.proj_mlp" if prefix else "proj_mlp")
+                                             quant_config=quant_config)
         self.proj_out = ColumnParallelLinear(dim + self.mlp_hidden_dim, dim, bias=True,
                                              gather_output=True, params_dtype=dtype,
-                                             quant_config=quant_config,
-                                             prefix=f"{prefix}.proj_out" if prefix else "proj_out")
+                                             quant_config=quant_config)
         self.attn = FluxAttention(query_dim=dim, dim_head=attention_head_dim,
                                   num_heads=num_attention_heads, out_dim=dim, bias=True, eps=1e-6,
-                                  pre_only=True, quant_config=quant_config,
-                                  prefix=f"{prefix}.attn" if prefix else "attn", dtype=dtype)
+                                  pre_only=True, quant_config=quant_config, dtype=dtype)
 
     def forward(self, hidden_states, encoder_hidden_states, temb, freqs_cis=None,
                 joint_attention_kwargs=None):
