@@ -114,7 +114,9 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="requests per GPU")
-    ap.add_argument("--mode", default="fp8", choices=["fp8", "bf16"])
+    ap.add_argument("--mode", default="fp8", choices=["fp8", "bf16", "fp8-block"],
+                    help="fp8: per-channel W8A8 quantised on the device (the metric); fp8-block: an "
+                         "fp8-serialised checkpoint with 128x128 weight blocks (NOT the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schnell", action="store_true",
                     help="Flux.1-schnell: no guidance embedder, bf16, batch 1, 4-step schedule "
@@ -154,7 +156,9 @@ def main():
         args.mode, args.batch, NUM_INFERENCE_STEPS = "bf16", 1, 4
     if args.layers:
         cfg.num_layers, cfg.num_single_layers = args.layers
-    qc = Fp8Config(is_checkpoint_fp8_serialized=False) if args.mode == "fp8" else None
+    qc = (Fp8Config(is_checkpoint_fp8_serialized=False) if args.mode == "fp8" else
+          Fp8Config(is_checkpoint_fp8_serialized=True, weight_block_size=[128, 128])
+          if args.mode == "fp8-block" else None)
     if args.checkpoint:
         from sglang_diffusion_amd.runtime.loader import get_component_config, load_flux_transformer
 
@@ -164,7 +168,12 @@ def main():
     else:
         with torch.device(dev):
             model = FluxTransformer2DModel(cfg, quant_config=qc)
-        init_synthetic_weights(model, seed=0, host_rng=False)
+        if args.mode == "fp8-block":
+            from sglang_diffusion_amd.runtime.synthetic import init_synthetic_block_fp8
+
+            init_synthetic_block_fp8(model, seed=0)
+        else:
+            init_synthetic_weights(model, seed=0, host_rng=False)
         model.process_weights_after_loading()
     stage = DenoisingStage(model, fused=True)
     B = args.batch
@@ -228,15 +237,16 @@ def main():
                          gbs=(v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0)
                  for k, v in classes.items()}
     # dominant kernel: the 256x256-tile GEMM of the mode's main dtype
-    dom = "gemm_fp8_256" if args.mode == "fp8" else "gemm_bf16_256"
-    peak = PEAK_FP8_TFLOPS if args.mode == "fp8" else PEAK_BF16_TFLOPS
+    dom = {"fp8": "gemm_fp8_256", "bf16": "gemm_bf16_256", "fp8-block": "gemm_fp8blk_128"}[args.mode]
+    peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_FP8_TFLOPS
     d = classes[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": None,
-                "kernel": ("gemm_kernel<1,4,2,2,4,false> (fp8 W8A8 linear, 256x256x128B tile)"
-                           if args.mode == "fp8" else
-                           "gemm_kernel<0,4,2,2,4,false> (bf16 linear, 256x256x128B tile)"),
+                "kernel": {"fp8": "gemm_kernel<1,4,2,2,4,false> (fp8 W8A8 linear, 256x256x128B tile)",
+                           "bf16": "gemm_kernel<0,4,2,2,4,false> (bf16 linear, 256x256x128B tile)",
+                           "fp8-block": "gemm_kernel<1,2,2,2,2,true> (block-scaled fp8 linear, "
+                                        "128x128x128B tile)"}[args.mode],
                 "launches_per_step": d["n"] // nsteps_traced,
                 "avg_launch_us": d["ms"] * 1e3 / d["n"],
                 "flop_per_launch": d["flops"] / d["n"]}
@@ -246,7 +256,8 @@ def main():
         import glob
 
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-        key = "gemm_kernel<1, 4, 2, 2, 4, false>" if args.mode == "fp8" else "gemm_kernel<0, 4, 2, 2, 4, false>"
+        key = {"fp8": "gemm_kernel<1, 4, 2, 2, 4, false>", "bf16": "gemm_kernel<0, 4, 2, 2, 4, false>",
+               "fp8-block": "gemm_kernel<1, 2, 2, 2, 2, true>"}[args.mode]
         roofline["traffic"] = json.load(open(pmc))["kernels"][key]["traffic_bytes_per_launch"]
         roofline["traffic_unit"] = "bytes per launch at the L2 memory side (2*FETCH_SIZE + WRITE_SIZE)"
         roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
@@ -273,8 +284,10 @@ def main():
         "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": ("fp8_e4m3 (W8A8 attention/single-block linears) + bf16 (FF, attention)"
-                  if args.mode == "fp8" else "bf16"),
+        "dtype": ("bf16" if args.mode == "bf16" else
+                  "fp8_e4m3 (W8A8 attention/single-block linears"
+                  + (", 128x128 weight blocks" if args.mode == "fp8-block" else "")
+                  + ") + bf16 (FF, attention)"),
         "data": ("synthetic inputs, weights from " + os.path.basename(os.path.normpath(args.checkpoint))
                  if args.checkpoint else "synthetic"),
         "config": {"workload": (("Flux.1-schnell" if args.schnell else "Flux.1-dev") + " DiT, 1024x1024 (4096 image + 512 text tokens), "

@@ -35,7 +35,9 @@ extern "C" {
 
 const char* mi355_last_error(void);
 /* 2: mi355_linear_args gained f16_begin/f16_end; mi355_flash_attn_fwd_f16v and
- *    mi355_bf16_to_f16 were added. */
+ *    mi355_bf16_to_f16 were added.
+ * 3: mi355_linear_args gained block_scale and the four scale strides;
+ *    mi355_layernorm_modulate_group_quant was added. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -147,6 +149,13 @@ typedef struct {
    * subnormal).  Used for the V third of a fused q|k|v projection that feeds
    * mi355_flash_attn_fwd_f16v.  Both multiples of 32; begin == end disables. */
   int64_t f16_begin, f16_end;
+  /* block_scale != 0 (with fp8 != 0): the arithmetic of mi355_fp8_blockwise_scaled_mm instead
+   * of per-token x per-channel scales -- sa is [M, K/128] (strides sa_sm, sa_sk; rows indexed
+   * by the MAPPED activation row), sb is [N/128, K/128] (strides sb_sn, sb_sk), the product is
+   * rounded to bf16 BEFORE the bias is added (fp8_utils.py:546-548), and everything after
+   * that (activation, gate/residual, row maps, half columns) works as in the other modes. */
+  int block_scale;
+  int64_t sa_sm, sa_sk, sb_sk, sb_sn;
 } mi355_linear_args;
 int mi355_linear_ex(const mi355_linear_args* args, void* stream);
 
@@ -242,6 +251,16 @@ int mi355_layernorm_modulate_quant(void* q, float* s, const void* x, const void*
                                    const void* scale, int64_t B, int64_t T, int64_t dim,
                                    int64_t ldx, int64_t ldmod, float eps,
                                    const mi355_rowmap* x_map, void* stream);
+
+/* Same, then dynamic quantisation per (token, 128-channel group)
+ * (mi355_per_token_group_quant_fp8 semantics with group_size 128, eps 1e-10, +-448):
+ * feeds the block-scaled fp8 linears.  s is dense [B*T, dim/128]; dim % 128 == 0.
+ * What Fp8LinearMethod.apply does per layer on a block-quantised checkpoint
+ * (python/sglang/srt/layers/quantization/fp8_utils.py:518-548), fused behind the norm. */
+int mi355_layernorm_modulate_group_quant(void* q, float* s, const void* x, const void* shift,
+                                         const void* scale, int64_t B, int64_t T, int64_t dim,
+                                         int64_t ldx, int64_t ldmod, float eps,
+                                         const mi355_rowmap* x_map, void* stream);
 
 /* out = residual + gate[b,:] * y with both bf16 roundings (flux.py:651-652,
  * 664-666, 671-688, 547-550).  y/residual/out [B*T, dim]. */

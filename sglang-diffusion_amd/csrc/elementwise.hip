@@ -234,8 +234,12 @@ __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions, u
 
 // ------------------------------------------------- layernorm + modulation ----
 // One wavefront per row, row in registers (NCH 16-byte chunks per lane).
-// QUANT: additionally per-token fp8 quantise the bf16 result.
-template <int NCH, bool QUANT>
+// QUANT 1: additionally per-token fp8 quantise the bf16 result (scale = absmax / 448,
+// q = x * (1/scale)).  QUANT 2: per (token, 128-channel group) instead, with the group
+// quantiser's arithmetic (absmax floored at 1e-10, q = x / scale, as
+// sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu:25-114); a group is the 16 lanes that hold
+// 128 consecutive channels of one chunk, scales are stored dense as [rows][dim / 128].
+template <int NCH, int QUANT>
 __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     void* __restrict__ out, float* __restrict__ qscale, const unsigned short* __restrict__ x,
     const unsigned short* __restrict__ shift, const unsigned short* __restrict__ scale, int64_t rows,
@@ -281,9 +285,11 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
   const u32x4* shr = shift ? reinterpret_cast<const u32x4*>(shift + b * ldmod) : nullptr;
   const u32x4* scr = scale ? reinterpret_cast<const u32x4*>(scale + b * ldmod) : nullptr;
   float amax = 0.f;
+  float gmax[QUANT == 2 ? NCH : 1];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int i = c * 64 + lane;
+    if constexpr (QUANT == 2) gmax[c] = 1e-10f;
     if (i < nvec) {
       float sc[8], sh[8];
       if (scr) unpack8(scr[i], sc);
@@ -294,17 +300,37 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
         if (scr) y = rbf(y * rbf(1.0f + sc[j]));  // * (1 + scale)
         if (shr) y = rbf(y + sh[j]);              // + shift
         v[c][j] = y;
-        amax = fmaxf(amax, fabsf(y));
+        if constexpr (QUANT == 2) gmax[c] = fmaxf(gmax[c], fabsf(y));
+        else amax = fmaxf(amax, fabsf(y));
       }
     }
   }
-  if constexpr (!QUANT) {
+  if constexpr (QUANT == 0) {
     const int64_t orow = map_row32((int)row, (int)om.rows_per_batch, om.batch_rows, om.row_offset);
     u32x4* op = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(out) + orow * ldo);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int i = c * 64 + lane;
       if (i < nvec) op[i] = pack8(v[c]);
+    }
+  } else if constexpr (QUANT == 2) {
+    const int ngrp = dim >> 7;
+    u32x2* op = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(out) + row * (int64_t)dim);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = c * 64 + lane;
+      const float y_s = group_max<16>(gmax[c]) / FP8_E4M3_MAX;  // every lane reaches the shuffle
+      if (i < nvec) {
+        if ((lane & 15) == 0) qscale[row * ngrp + (i >> 4)] = y_s;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          f[j] = clamp_fp8(v[c][j] / y_s, -FP8_E4M3_MAX, FP8_E4M3_MAX);
+        u32x2 o;
+        o[0] = cvt4_fp8(f[0], f[1], f[2], f[3]);
+        o[1] = cvt4_fp8(f[4], f[5], f[6], f[7]);
+        op[i] = o;
+      }
     }
   } else {
     amax = group_max<64>(amax);
@@ -569,7 +595,7 @@ extern "C" int mi355_rotary_embedding(const int64_t* positions, void* q, void* k
 static int launch_ln_mod(void* out, float* qscale, const void* x, const void* shift,
                          const void* scale, int64_t B, int64_t T, int64_t dim, int64_t ldx,
                          int64_t ldo, int64_t ldmod, float eps, const mi355_rowmap* x_map,
-                         const mi355_rowmap* o_map, bool quant, void* stream) {
+                         const mi355_rowmap* o_map, int quant, void* stream) {
   MI355_REQUIRE(out && x, "layernorm_modulate: null pointer");
   MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0 && dim <= 16384,
                 "layernorm_modulate: dim (%ld) must be a multiple of 8 and <= 16384", (long)dim);
@@ -589,12 +615,14 @@ static int launch_ln_mod(void* out, float* qscale, const void* x, const void* sh
                      (const unsigned short*)x, (const unsigned short*)shift,                      \
                      (const unsigned short*)scale, rows, (int)T, (int)dim, ldx, ldo, ldmod, eps,  \
                      xm, om)
-#define LNQ(N)       \
-  do {               \
-    if (quant)       \
-      LN(N, true);   \
-    else             \
-      LN(N, false);  \
+#define LNQ(N)          \
+  do {                  \
+    if (quant == 2)     \
+      LN(N, 2);         \
+    else if (quant)     \
+      LN(N, 1);         \
+    else                \
+      LN(N, 0);         \
   } while (0)
   if (nch <= 1) LNQ(1);
   else if (nch <= 2) LNQ(2);
@@ -615,7 +643,7 @@ extern "C" int mi355_layernorm_modulate(void* out, const void* x, const void* sh
                                         const mi355_rowmap* x_map, const mi355_rowmap* o_map,
                                         void* stream) {
   return launch_ln_mod(out, nullptr, x, shift, scale, B, T, dim, ldx, ldo, ldmod, eps, x_map,
-                       o_map, false, stream);
+                       o_map, 0, stream);
 }
 
 extern "C" int mi355_layernorm_modulate_quant(void* q, float* s, const void* x, const void* shift,
@@ -624,7 +652,19 @@ extern "C" int mi355_layernorm_modulate_quant(void* q, float* s, const void* x, 
                                               const mi355_rowmap* x_map, void* stream) {
   MI355_REQUIRE(s != nullptr, "layernorm_modulate_quant: null scale output");
   return launch_ln_mod(q, s, x, shift, scale, B, T, dim, ldx, /*ldo*/ 8, ldmod, eps, x_map,
-                       nullptr, true, stream);
+                       nullptr, 1, stream);
+}
+
+extern "C" int mi355_layernorm_modulate_group_quant(void* q, float* s, const void* x,
+                                                    const void* shift, const void* scale,
+                                                    int64_t B, int64_t T, int64_t dim, int64_t ldx,
+                                                    int64_t ldmod, float eps,
+                                                    const mi355_rowmap* x_map, void* stream) {
+  MI355_REQUIRE(s != nullptr, "layernorm_modulate_group_quant: null scale output");
+  MI355_REQUIRE(dim % 128 == 0, "layernorm_modulate_group_quant: dim (%ld) must be a multiple of 128",
+                (long)dim);
+  return launch_ln_mod(q, s, x, shift, scale, B, T, dim, ldx, /*ldo*/ 8, ldmod, eps, x_map,
+                       nullptr, 2, stream);
 }
 
 extern "C" int mi355_gate_residual(void* out, const void* residual, const void* gate,

@@ -94,6 +94,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           for (int e = 0; e < 4; ++e) {
             float v = acc[i][j][4 * g + e];
             if constexpr (DT == 1 && !BLOCKSCALE) v = v * sam * sbv[e];
+            // the block-scaled linear casts the product to bf16 and THEN adds the bias
+            // (python/sglang/srt/layers/quantization/fp8_utils.py:546-548)
+            if constexpr (BLOCKSCALE) v = rbf(v);
             v += bsv[e];
             if (p.act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
             y[e] = v;
@@ -285,9 +288,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
     if constexpr (BLOCKSCALE) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        int64_t m = m0 + wm * TM * 32 + j * 32 + r;
+        int m = m0 + wm * TM * 32 + j * 32 + r;
         if (m >= p.M) m = p.M - 1;
-        sa_row[j] = p.sa + m * p.sa_sm;
+        // group scales live beside the activation rows: index by the mapped A row
+        sa_row[j] = p.sa + map_row32(m, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
+                                     p.a_map.row_offset) * p.sa_sm;
       }
     }
 
@@ -559,9 +564,12 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
                     (!a->gate || (a->ldg % 8 == 0 && ((uintptr_t)a->gate % 16) == 0 &&
                                   ((uintptr_t)a->residual % 16) == 0)),
                 "linear: output/gate/residual rows must be 16-byte aligned");
-  MI355_REQUIRE(!a->fp8 || ((uintptr_t)a->sb % 16) == 0, "fp8 linear: scales_b must be 16-byte aligned");
+  MI355_REQUIRE(!a->fp8 || a->block_scale || ((uintptr_t)a->sb % 16) == 0,
+                "fp8 linear: scales_b must be 16-byte aligned");
   MI355_REQUIRE(!a->bias || ((uintptr_t)a->bias % 8) == 0, "linear: bias must be 8-byte aligned");
   if (a->fp8) MI355_REQUIRE(a->sa && a->sb, "fp8 linear: scales missing");
+  MI355_REQUIRE(!a->block_scale || (a->fp8 && a->K % 128 == 0),
+                "linear: block scales need the fp8 path and K %% 128 == 0");
   GemmParams p;
   p.a = (const unsigned char*)a->a;
   p.w = (const unsigned char*)a->w;
@@ -585,6 +593,13 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
   p.f16_begin = (int)a->f16_begin;
   p.f16_end = (int)a->f16_end;
   p.sa_sm = p.sa_sk = p.sb_sk = p.sb_sn = 0;
+  if (a->block_scale) {
+    p.sa_sm = a->sa_sm;
+    p.sa_sk = a->sa_sk;
+    p.sb_sk = a->sb_sk;
+    p.sb_sn = a->sb_sn;
+    return launch_gemm<1, 2, 2, 2, 2, true>(p, st);
+  }
   // Tile choice: 256x256 (8 waves) when the grid still covers the chip, else 128x128.
   const int64_t big_tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
   const bool big = big_tiles >= 192;
@@ -648,22 +663,23 @@ extern "C" int mi355_fp8_blockwise_scaled_mm(const void* a, const void* b, const
   MI355_REQUIRE(N % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out % 16) == 0,
                 "fp8_blockwise_scaled_mm: N and output rows must be 16-byte multiples");
   if (M == 0) return MI355_OK;
-  GemmParams p = {};
-  p.a = (const unsigned char*)a;
-  p.w = (const unsigned char*)b;
-  p.sa = sa;
-  p.sb = sb;
-  p.out = (unsigned short*)out;
-  p.M = (int)M;
-  p.N = (int)N;
-  p.ktiles = (int)(K / 128);
-  p.lda_b = lda;
-  p.ldw_b = ldb;
-  p.ldo = ldo;
-  p.gate_rows = 1;
-  p.sa_sm = sa_sm;
-  p.sa_sk = sa_sk;
-  p.sb_sk = sb_sk;
-  p.sb_sn = sb_sn;
-  return launch_gemm<1, 2, 2, 2, 2, true>(p, (hipStream_t)stream);
+  mi355_linear_args g = {};
+  g.a = a;
+  g.w = b;
+  g.sa = sa;
+  g.sb = sb;
+  g.out = out;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = lda;
+  g.ldw = ldb;
+  g.ldo = ldo;
+  g.fp8 = 1;
+  g.block_scale = 1;
+  g.sa_sm = sa_sm;
+  g.sa_sk = sa_sk;
+  g.sb_sk = sb_sk;
+  g.sb_sn = sb_sn;
+  return mi355_linear_ex(&g, stream);
 }

@@ -52,6 +52,11 @@ class LinearArgs(ctypes.Structure):
         ("act", _int),
         ("f16_begin", _i64),
         ("f16_end", _i64),
+        ("block_scale", _int),
+        ("sa_sm", _i64),
+        ("sa_sk", _i64),
+        ("sb_sk", _i64),
+        ("sb_sn", _i64),
     ]
 
 
@@ -93,6 +98,10 @@ SIGNATURES = {
         [_ptr] * 4 + [_i64] * 6 + [_f32, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), _ptr],
     ),
     "mi355_layernorm_modulate_quant": (
+        _int,
+        [_ptr] * 5 + [_i64] * 5 + [_f32, ctypes.POINTER(RowMap), _ptr],
+    ),
+    "mi355_layernorm_modulate_group_quant": (
         _int,
         [_ptr] * 5 + [_i64] * 5 + [_f32, ctypes.POINTER(RowMap), _ptr],
     ),
@@ -224,7 +233,10 @@ def linear_bf16(x, w, bias, out, act: int = 0) -> None:
 def linear_ex(
     a, w, out, *, M, N, K, lda, ldw, ldo, sa=None, sb=None, bias=None, residual=None, gate=None,
     ldg=0, gate_rows=0, a_map=None, o_map=None, fp8=False, act=0, f16_cols=None,
+    block_scale=False,
 ) -> None:
+    """block_scale: `sa` is the [rows, K/128] group-scale tensor of the activations and `sb` the
+    [N/128, K/128] block-scale tensor of the weight (their strides are taken from the tensors)."""
     args = LinearArgs()
     args.a, args.w, args.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
     args.sa, args.sb, args.bias = _p(sa), _p(sb), _p(bias)
@@ -237,6 +249,10 @@ def linear_ex(
     args.fp8 = int(bool(fp8))
     args.act = int(act)
     args.f16_begin, args.f16_end = (f16_cols if f16_cols else (0, 0))
+    if block_scale:
+        args.block_scale = 1
+        args.sa_sm, args.sa_sk = sa.stride(0), sa.stride(1)
+        args.sb_sn, args.sb_sk = sb.stride(0), sb.stride(1)
     _check(load_library().mi355_linear_ex(ctypes.byref(args), _stream(a)), "linear_ex")
 
 
@@ -377,6 +393,23 @@ def layernorm_modulate_quant(q, s, x, shift, scale, B, T, eps, x_map=None) -> No
             ctypes.byref(xm) if xm else None, _stream(x),
         ),
         "layernorm_modulate_quant",
+    )
+
+
+def layernorm_modulate_group_quant(q, s, x, shift, scale, B, T, eps, x_map=None) -> None:
+    """As layernorm_modulate_quant with one scale per (row, 128 channels): s is [B*T, dim/128]."""
+    dim = x.shape[-1]
+    xm = _rowmap(x_map)
+    mod = shift if shift is not None else scale
+    if not s.is_contiguous() or s.shape[-1] != dim // 128:
+        raise RuntimeError("layernorm_modulate_group_quant: scales must be dense [rows, dim/128]")
+    _check(
+        load_library().mi355_layernorm_modulate_group_quant(
+            q.data_ptr(), s.data_ptr(), x.data_ptr(), _p(shift), _p(scale), B, T, dim,
+            x.stride(-2), mod.stride(0) if mod is not None else 8, float(eps),
+            ctypes.byref(xm) if xm else None, _stream(x),
+        ),
+        "layernorm_modulate_group_quant",
     )
 
 

@@ -307,7 +307,6 @@ class FluxTransformer2DModel(nn.Module):
                                              c.patch_size * c.patch_size * self.out_channels,
                                              bias=True, gather_output=True, params_dtype=dtype)
         self._engine = None
-        self._block_quant = None
 
     # ------------------------------------------------------------------ weights --
     def process_weights_after_loading(self) -> None:
@@ -318,7 +317,6 @@ class FluxTransformer2DModel(nn.Module):
             if qm is not None:
                 qm.process_weights_after_loading(m)
         self._engine = None
-        self._block_quant = None
 
     # ------------------------------------------------------------------ forward --
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor = None,
@@ -346,18 +344,9 @@ class FluxTransformer2DModel(nn.Module):
     def forward_fused(self, hidden_states, encoder_hidden_states=None, pooled_projections=None,
                       timestep=None, guidance=None, freqs_cis=None,
                       joint_attention_kwargs=None) -> torch.Tensor:
-        """Same contract as `forward`, executed by the fused engine.  Block-quantised
-        checkpoints (128x128 weight blocks, per-token-group activation scales) have no fused
-        schedule yet and run layer by layer through `forward`, on the same kernels."""
-        from ..layers.quantization import Fp8LinearMethod
+        """Same contract as `forward`, executed by the fused engine."""
         from .flux_engine import FluxEngine
 
-        if self._block_quant is None:
-            self._block_quant = any(isinstance(getattr(m, "quant_method", None), Fp8LinearMethod)
-                                    and m.quant_method.block_quant for m in self.modules())
-        if self._block_quant:
-            return self.forward(hidden_states, encoder_hidden_states, pooled_projections, timestep,
-                                guidance, freqs_cis, joint_attention_kwargs)
         if self._engine is None:
             self._engine = FluxEngine(self)
         return self._engine.step(hidden_states, encoder_hidden_states, pooled_projections,

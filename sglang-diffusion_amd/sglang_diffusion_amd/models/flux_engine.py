@@ -16,8 +16,12 @@ the hardware:
     hidden state; `gate * y + residual` is the epilogue of the GEMM that produces y.
   * All 19*2 + 38 + 1 AdaLN modulation linears are one weight-streaming GEMM per step.
 
-Per-token fp8 scales, fp8 activations and all intermediates are caller-invisible workspace
-tensors allocated once per (batch, sequence) shape.
+Block-quantised checkpoints (128x128 weight blocks, activations quantised per token and 128
+channels) run the same schedule: the norm kernel emits group scales, the GEMM rescales every
+K tile, and the product is rounded to bf16 before the bias as the layer path does.
+
+fp8 scales, fp8 activations and all intermediates are caller-invisible workspace tensors
+allocated once per (batch, sequence) shape.
 """
 from __future__ import annotations
 
@@ -29,12 +33,14 @@ from .. import _C
 from ..layers.quantization import FP8_DTYPE, Fp8LinearMethod, UnquantizedLinearMethod
 
 
+def _is_block(lin) -> bool:
+    qm = lin.quant_method
+    return isinstance(qm, Fp8LinearMethod) and qm.block_quant
+
+
 def _is_fp8(lin) -> bool:
     qm = lin.quant_method
     if isinstance(qm, Fp8LinearMethod):
-        if qm.block_quant:
-            raise NotImplementedError("block-quantised checkpoints run through `forward` "
-                                      "(module path); the fused engine is per-channel only")
         if lin.weight.dtype != FP8_DTYPE:
             raise RuntimeError("call process_weights_after_loading() before the fused path")
         return True
@@ -43,23 +49,38 @@ def _is_fp8(lin) -> bool:
 
 
 class _Packed:
-    """Several linears concatenated along N; the modules' parameters become views."""
+    """Several linears concatenated along N; the modules' parameters become views.
+
+    fp8 with per-channel scales: `s` is [N].  fp8 from a block-quantised checkpoint
+    (`block`): `s` is the [N/128, K/128] block-scale matrix, which concatenates along N like
+    the weight as long as every member's N is a multiple of 128."""
 
     def __init__(self, lins: List):
         self.fp8 = _is_fp8(lins[0])
-        assert all(_is_fp8(l) == self.fp8 for l in lins)
+        self.block = _is_block(lins[0])
+        assert all(_is_fp8(l) == self.fp8 and _is_block(l) == self.block for l in lins)
         self.w = torch.cat([l.weight.data for l in lins], dim=0).contiguous()
         self.b = (torch.cat([l.bias.data for l in lins], dim=0).contiguous()
                   if lins[0].bias is not None else None)
-        self.s = (torch.cat([l.weight_scale.data.reshape(-1) for l in lins]).contiguous()
-                  if self.fp8 else None)
-        o = 0
+        self.s = None
+        if self.block:
+            if len(lins) > 1 and any(l.weight.shape[0] % 128 for l in lins):
+                raise NotImplementedError("fusing block-quantised projections needs output "
+                                          "widths that are multiples of 128")
+            self.s = torch.cat([l.weight_scale_inv.data for l in lins], dim=0).contiguous()
+        elif self.fp8:
+            self.s = torch.cat([l.weight_scale.data.reshape(-1) for l in lins]).contiguous()
+        o = so = 0
         for l in lins:  # re-point the module parameters at the packed storage (no 2nd copy)
             n = l.weight.shape[0]
             l.weight.data = self.w[o:o + n]
             if self.b is not None:
                 l.bias.data = self.b[o:o + n]
-            if self.fp8:
+            if self.block:
+                nb = l.weight_scale_inv.shape[0]
+                l.weight_scale_inv.data = self.s[so:so + nb]
+                so += nb
+            elif self.fp8:
                 l.weight_scale.data = self.s[o:o + n]
             o += n
         self.N, self.K = self.w.shape
@@ -118,6 +139,14 @@ class FluxEngine:
                 qkv=_Packed([a.to_q, a.to_k, a.to_v]), mlp=_Packed([blk.proj_mlp]),
                 out=_Packed([blk.proj_out]), nq=a.norm_q.weight.data, nk=a.norm_k.weight.data,
                 eps=a.norm_q.variance_epsilon))
+        packs = [pk for blk in self.dbl + self.sgl for pk in blk.values()
+                 if isinstance(pk, _Packed) and pk.fp8]
+        self.block = bool(packs) and packs[0].block
+        if any(pk.block != self.block for pk in packs):
+            raise NotImplementedError("per-channel and block-quantised layers in one model")
+        if self.block and (D % 128 or (D + (model.single_transformer_blocks[0].mlp_hidden_dim
+                                            if self.sgl else 0)) % 128):
+            raise NotImplementedError("block-quantised fused path needs widths % 128 == 0")
         self._ws: Dict[Tuple, dict] = {}
         # optional per-launch timing: list of (kind, flops, bytes, start_event, end_event)
         self.trace: Optional[list] = None
@@ -145,12 +174,15 @@ class FluxEngine:
         mlp = self.model.single_transformer_blocks[0].mlp_hidden_dim \
             if len(self.model.single_transformer_blocks) else 4 * D
         e = lambda *shape, dtype=bf: torch.empty(shape, dtype=dtype, device=dev)  # noqa: E731
+        # activation scales: one per token, or one per (token, 128 channels) for block checkpoints
+        sc = (lambda width: e(Ms, width // 128, dtype=f32)) if self.block \
+            else (lambda width: e(Ms, dtype=f32))
         ws = dict(
             joint=e(Ms, D), mod=e(B, self.n_mod), silu_temb=e(B, D),
-            xq=e(Ms, D, dtype=f8), xs=e(Ms, dtype=f32), xn=e(Ms, D),
-            qkv=e(Ms, 3 * D), attn=e(Ms, D), aq=e(Ms, D, dtype=f8), as_=e(Ms, dtype=f32),
+            xq=e(Ms, D, dtype=f8), xs=sc(D), xn=e(Ms, D),
+            qkv=e(Ms, 3 * D), attn=e(Ms, D), aq=e(Ms, D, dtype=f8), as_=sc(D),
             ffh=e(max(Mi, Mt), 4 * D), cat=e(Ms, D + mlp), cq=e(Ms, D + mlp, dtype=f8),
-            cs=e(Ms, dtype=f32), out=e(Mi, self.model.proj_out.weight.shape[0]),
+            cs=sc(D + mlp), out=e(Mi, self.model.proj_out.weight.shape[0]),
         )
         self._ws[key] = ws
         return ws
@@ -159,15 +191,16 @@ class FluxEngine:
     def _lin(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
              gate=None, gate_rows=0, act=0, ldo=None, lda=None, f16_cols=None):
         # same tile rule as csrc/gemm.hip: the 256x256 kernel when it yields >= 192 tiles
-        big = ((M + 255) // 256) * ((pk.N + 255) // 256) >= 192
-        self._run(("gemm_fp8" if pk.fp8 else "gemm_bf16") + ("_256" if big else "_128"),
+        big = ((M + 255) // 256) * ((pk.N + 255) // 256) >= 192 and not pk.block
+        self._run(("gemm_fp8blk" if pk.block else "gemm_fp8" if pk.fp8 else "gemm_bf16")
+                  + ("_256" if big else "_128"),
                   2.0 * M * pk.N * pk.K,
                   (M * pk.K + pk.N * pk.K) * (1 if pk.fp8 else 2) + 2.0 * M * pk.N,
                   _C.linear_ex, a, pk.w, out, M=M, N=pk.N, K=pk.K, lda=lda or a.stride(0),
                   ldw=pk.w.stride(0), ldo=ldo or out.stride(0), sa=sa, sb=pk.s, bias=pk.b,
                   residual=residual, gate=gate, ldg=gate.stride(0) if gate is not None else 0,
                   gate_rows=gate_rows, a_map=a_map, o_map=o_map, fp8=pk.fp8, act=act,
-                  f16_cols=f16_cols)
+                  f16_cols=f16_cols, block_scale=pk.block)
 
     def _lin_mod(self, mod, a, out, *, M, o_map=None, residual=None, gate=None, gate_rows=0, act=0):
         """Unquantised nn.Linear-style module (FF, embedders)."""
@@ -226,11 +259,19 @@ class FluxEngine:
         # kernel multiplies half probabilities with half values
         vcols = (2 * D, 3 * D)
 
+        if self.block:
+            def quant(x, q, s_):  # per (token, 128 channels), fp8.py:303-352 on a block checkpoint
+                _C.per_token_group_quant_fp8(x, q, s_, 128, 1e-10, -448.0, 448.0, False)
+        else:
+            quant = _C.per_token_quant_fp8
+
         def norm_in(pk_fp8, shift, scl, T, rmap, M):
             """LayerNorm + modulation (+ fp8 quant) of one stream -> (activation, scales)."""
             if pk_fp8:
-                self._run("elementwise", 0.0, 3.0 * M * D, _C.layernorm_modulate_quant, ws["xq"],
-                          ws["xs"], joint, shift, scl, B, T, 1e-6, x_map=rmap)
+                fn = (_C.layernorm_modulate_group_quant if self.block
+                      else _C.layernorm_modulate_quant)
+                self._run("elementwise", 0.0, 3.0 * M * D, fn, ws["xq"], ws["xs"], joint, shift,
+                          scl, B, T, 1e-6, x_map=rmap)
                 return ws["xq"], ws["xs"]
             self._run("elementwise", 0.0, 4.0 * M * D, _C.layernorm_modulate, ws["xn"], joint,
                       shift, scl, B, T, 1e-6, x_map=rmap)
@@ -248,8 +289,7 @@ class FluxEngine:
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
                       attn4, None, scale, False, True)
             if blk["to_out"].fp8:
-                self._run("elementwise", 0.0, 3.0 * Ms * D, _C.per_token_quant_fp8, attn, ws["aq"],
-                          ws["as_"])
+                self._run("elementwise", 0.0, 3.0 * Ms * D, quant, attn, ws["aq"], ws["as_"])
                 a_src, a_s = ws["aq"], ws["as_"]
             else:
                 a_src, a_s = attn, None
@@ -282,8 +322,7 @@ class FluxEngine:
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
                       attn_in_cat, None, scale, False, True)
             if blk["out"].fp8:
-                self._run("elementwise", 0.0, 3.0 * Ms * catw, _C.per_token_quant_fp8, cat,
-                          ws["cq"], ws["cs"])
+                self._run("elementwise", 0.0, 3.0 * Ms * catw, quant, cat, ws["cq"], ws["cs"])
                 c_src, c_s = ws["cq"], ws["cs"]
             else:
                 c_src, c_s = cat, None

@@ -36,6 +36,36 @@ def init_synthetic_weights(model, seed: int = 0, host_rng: bool = True) -> None:
         p.data.copy_(w.to(p.dtype))
 
 
+@torch.no_grad()
+def init_synthetic_block_fp8(model, seed: int = 0, block=(128, 128)) -> None:
+    """Fill a model built for an fp8-SERIALISED block-quantised checkpoint: every fp8 weight is
+    drawn like init_synthetic_weights draws its bf16 original on the device and then goes
+    through the offline converter's block rule (tools/convert_hf_to_fp8.py); everything else is
+    initialised as usual."""
+    from ..tools.convert_hf_to_fp8 import block_fp8
+
+    params = dict(model.named_parameters())
+    for name, p in params.items():
+        if name.endswith(".weight_scale_inv"):
+            continue
+        if p.dtype == torch.float8_e4m3fn:
+            g = torch.Generator(device=p.device)
+            g.manual_seed(_seed_for(name, seed))
+            w = (torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32)
+                 * (p.shape[1] ** -0.5)).to(torch.bfloat16)
+            q, s_ = block_fp8(w, block)
+            p.data.copy_(q)
+            params[name[:-len("weight")] + "weight_scale_inv"].data.copy_(s_)
+        elif p.dtype == torch.float32 and p.dim() == 1:
+            p.data.fill_(1.0)
+        else:
+            g = torch.Generator(device=p.device)
+            g.manual_seed(_seed_for(name, seed))
+            std = (p.shape[1] ** -0.5) if p.dim() == 2 else 0.02
+            p.data.copy_((torch.randn(p.shape, generator=g, device=p.device,
+                                      dtype=torch.float32) * std).to(p.dtype))
+
+
 def make_synthetic_request(batch_size: int, height: int = 1024, width: int = 1024,
                            num_inference_steps: int = 50, device="cuda", seed: int = 0,
                            true_cfg: bool = False, guidance_scale: float = 3.5,

@@ -107,7 +107,12 @@ def test_block_quantised_fp8_checkpoint_end_to_end(device):
                               height=128, width=96, num_steps=2)
     for name in ("latents", "prompt_embeds", "pooled_embeds"):
         setattr(req, name, getattr(req, name).to(device))
-    out = DenoisingStage(model, fused=True).forward(req).latents   # falls back to the layer path
+    import copy
+
+    out_layers = DenoisingStage(model, fused=False).forward(copy.copy(req)).latents
+    out = DenoisingStage(model, fused=True).forward(copy.copy(req)).latents
     e = rel_l2(out, ref)
     print(f"block-quantised checkpoint, 2 steps: rel {e:.2e}")
     assert e <= 2.5e-2
+    # the fused schedule keeps every rounding point of the layer path
+    assert torch.equal(out, out_layers)

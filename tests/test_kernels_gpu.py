@@ -196,6 +196,82 @@ def test_linear_ex_rowmaps_gate_residual(device):
     assert rel_l2(got[:, Tt:], exp[:, Tt:]) <= 1e-3
 
 
+def test_linear_ex_block_scaled_epilogues(device):
+    """The block-scaled GEMM behind the fused epilogues (bias after the bf16 cast, GELU, joint
+    row maps with group scales indexed by the mapped row, gate/residual, half columns) gives
+    the bits of mi355_fp8_blockwise_scaled_mm followed by the separate eager ops."""
+    B, Ti, Tt, D, N = 2, 96, 32, 256, 384
+    S = Ti + Tt
+    x = torch.randn(B * S, D, generator=g(61)).bfloat16()
+    w = (torch.randn(N, D, generator=g(62)) * D ** -0.5).bfloat16()
+    bias = (torch.randn(N, generator=g(63)) * 0.1).bfloat16().to(device)
+    gate = torch.randn(B, 3 * N, generator=g(64)).bfloat16().to(device)
+    res = torch.randn(B * S, N, generator=g(65)).bfloat16().to(device)
+    xq, xs = ops.per_token_group_quant_fp8(x, 128)
+    wq, wsc = ops.quantize_weight_block(w)
+    xq, xs, wq, wsc = xq.to(device), xs.to(device), wq.to(device), wsc.to(device)
+
+    def plain(rows_q, rows_s):
+        out = torch.empty(rows_q.shape[0], N, dtype=torch.bfloat16, device=device)
+        _C.fp8_blockwise_scaled_mm(rows_q, wq, rows_s, wsc, out, (rows_s.stride(0), rows_s.stride(1)),
+                                   (wsc.stride(1), wsc.stride(0)))
+        return out
+
+    base = plain(xq, xs)
+    # bias, then GELU
+    got = torch.empty_like(base)
+    _C.linear_ex(xq, wq, got, M=B * S, N=N, K=D, lda=D, ldw=D, ldo=N, sa=xs, sb=wsc, bias=bias,
+                 fp8=True, block_scale=True)
+    want = base + bias
+    assert torch.equal(got, want)
+    _C.linear_ex(xq, wq, got, M=B * S, N=N, K=D, lda=D, ldw=D, ldo=N, sa=xs, sb=wsc, bias=bias,
+                 fp8=True, block_scale=True, act=1)
+    gelu = torch.empty_like(want)
+    _C.activation(gelu, want, 1)
+    assert torch.equal(got, gelu)
+    # image rows of the joint buffer, gate * y + residual written back in place
+    out = res.clone()
+    _C.linear_ex(xq, wq, out, M=B * Ti, N=N, K=D, lda=D, ldw=D, ldo=N, sa=xs, sb=wsc, bias=bias,
+                 residual=out, gate=gate[:, N:2 * N], ldg=gate.stride(0), gate_rows=Ti,
+                 a_map=(Ti, S, Tt), o_map=(Ti, S, Tt), fp8=True, block_scale=True)
+    exp = res.clone().view(B, S, N)
+    y = want.view(B, S, N)[:, Tt:]
+    exp[:, Tt:] = exp[:, Tt:] + gate[:, None, N:2 * N] * y
+    assert torch.equal(out.view(B, S, N), exp)
+    # half columns
+    mixed = torch.empty_like(base)
+    _C.linear_ex(xq, wq, mixed, M=B * S, N=N, K=D, lda=D, ldw=D, ldo=N, sa=xs, sb=wsc, bias=bias,
+                 fp8=True, block_scale=True, f16_cols=(256, 384))
+    assert torch.equal(mixed[:, :256], want[:, :256])
+    assert torch.equal(_f16_bits_to_float(mixed[:, 256:].contiguous()), want[:, 256:].float().cpu())
+
+
+@pytest.mark.parametrize("B,T,dim,mapped", [(2, 50, 256, False), (3, 33, 3072, True), (1, 7, 128, False)])
+def test_layernorm_modulate_group_quant(device, B, T, dim, mapped):
+    """LayerNorm + modulation + per-(token, 128 channels) quantisation in one pass == the
+    bf16 kernel followed by mi355_per_token_group_quant_fp8, bit for bit."""
+    extra = 5 if mapped else 0
+    x = (torch.randn(B * (T + extra), dim, generator=g(71)) * 2).bfloat16().to(device)
+    if B > 1:
+        x[1, 128:256] = 0  # an all-zero group after modulation is still possible only via scale
+    shift = torch.randn(B, dim, generator=g(72)).bfloat16().to(device)
+    scale = (torch.randn(B, dim, generator=g(73)) * 0.3).bfloat16().to(device)
+    xm = (T, T + extra, extra) if mapped else None
+    y = torch.empty(B * T, dim, dtype=torch.bfloat16, device=device)
+    _C.layernorm_modulate(y, x, shift, scale, B, T, 1e-6, x_map=xm)
+    q0 = torch.empty(B * T, dim, dtype=torch.float8_e4m3fn, device=device)
+    s0 = torch.empty(B * T, dim // 128, dtype=torch.float32, device=device)
+    _C.per_token_group_quant_fp8(y, q0, s0, 128, 1e-10, -448.0, 448.0, False)
+    q1 = torch.empty_like(q0)
+    s1 = torch.empty_like(s0)
+    _C.layernorm_modulate_group_quant(q1, s1, x, shift, scale, B, T, 1e-6, x_map=xm)
+    assert torch.equal(s1, s0)
+    assert torch.equal(q1.view(torch.uint8), q0.view(torch.uint8))
+    with pytest.raises(RuntimeError):
+        _C.layernorm_modulate_group_quant(q1[:, :64], s1[:, :1].contiguous(), x[:, :64].contiguous(),
+                                          None, None, B, T, 1e-6)
+
+
 # --------------------------------------------------------------------------- attention --
 @pytest.mark.parametrize("B,Sq,Sk,H,Hk,D", [(1, 128, 128, 2, 2, 128), (2, 333, 333, 3, 3, 128),
                                              (1, 1, 65, 2, 1, 128), (1, 200, 77, 4, 2, 64),
