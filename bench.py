@@ -237,7 +237,7 @@ def main():
                          gbs=(v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0)
                  for k, v in classes.items()}
     # dominant kernel: the 256x256-tile GEMM of the mode's main dtype
-    dom = {"fp8": "gemm_fp8_256", "bf16": "gemm_bf16_256", "fp8-block": "gemm_fp8blk_128"}[args.mode]
+    dom = {"fp8": "gemm_fp8_256", "bf16": "gemm_bf16_256", "fp8-block": "gemm_fp8blk_256"}[args.mode]
     peak = PEAK_BF16_TFLOPS if args.mode == "bf16" else PEAK_FP8_TFLOPS
     d = classes[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -245,8 +245,8 @@ def main():
                 "frac": ach / peak, "traffic": None,
                 "kernel": {"fp8": "gemm_kernel<1,4,2,2,4,false> (fp8 W8A8 linear, 256x256x128B tile)",
                            "bf16": "gemm_kernel<0,4,2,2,4,false> (bf16 linear, 256x256x128B tile)",
-                           "fp8-block": "gemm_kernel<1,2,2,2,2,true> (block-scaled fp8 linear, "
-                                        "128x128x128B tile)"}[args.mode],
+                           "fp8-block": "gemm_kernel<1,4,2,2,4,true> (block-scaled fp8 linear, "
+                                        "256x256x128B tile)"}[args.mode],
                 "launches_per_step": d["n"] // nsteps_traced,
                 "avg_launch_us": d["ms"] * 1e3 / d["n"],
                 "flop_per_launch": d["flops"] / d["n"]}
@@ -257,7 +257,7 @@ def main():
 
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
         key = {"fp8": "gemm_kernel<1, 4, 2, 2, 4, false>", "bf16": "gemm_kernel<0, 4, 2, 2, 4, false>",
-               "fp8-block": "gemm_kernel<1, 2, 2, 2, 2, true>"}[args.mode]
+               "fp8-block": "gemm_kernel<1, 4, 2, 2, 4, true>"}[args.mode]
         roofline["traffic"] = json.load(open(pmc))["kernels"][key]["traffic_bytes_per_launch"]
         roofline["traffic_unit"] = "bytes per launch at the L2 memory side (2*FETCH_SIZE + WRITE_SIZE)"
         roofline["traffic_source"] = os.path.relpath(pmc, ROOT)

@@ -285,7 +285,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
 
     // block-scaled variant: scale row pointers
     const float* sa_row[TM];
+    float sa_cur[TM];  // this K tile's activation scales, fetched one tile ahead
+    const float* sb_col = nullptr;
+    float sb_cur = 1.f;
+    // software pipeline of the block-scaled K loop: two partial tiles, and the scale of the
+    // unit still waiting to be added (the last unit of the previous K tile)
+    static_assert(!BLOCKSCALE || (TN * TM) % 2 == 0, "the last unit of a K tile uses part[1]");
+    f32x16 part[2];
+    float pend_f = 0.f;
     if constexpr (BLOCKSCALE) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) part[1][e] = 0.f;
+    }  // this K tile's weight-block scale, fetched one tile ahead as well
+    if constexpr (BLOCKSCALE) {
+      // a wave's channels (TN * 32 <= 128, aligned) lie inside one 128-channel scale block
+      static_assert(TN * 32 <= 128 && 128 % (TN * 32) == 0, "one weight scale per wave and K tile");
+      int nb = (n0 + wn * TN * 32) >> 7;
+      const int nb_max = (p.N - 1) >> 7;
+      if (nb > nb_max) nb = nb_max;
+      sb_col = p.sb + nb * p.sb_sn;
+      sb_cur = sb_col[0];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         int m = m0 + wm * TM * 32 + j * 32 + r;
@@ -293,6 +312,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
         // group scales live beside the activation rows: index by the mapped A row
         sa_row[j] = p.sa + map_row32(m, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
                                      p.a_map.row_offset) * p.sa_sm;
+        sa_cur[j] = sa_row[j][0];
       }
     }
 
@@ -303,79 +323,121 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
       if (kt + 1 < p.ktiles) stage(cur ^ 1);
       const unsigned char* sbase = smem + cur * STAGE_BYTES;
 
-      f32x16 part[TN][TM];
       if constexpr (BLOCKSCALE) {
+        // One K tile is one 128-wide scale block.  The K tile is walked in TN*TM units of one
+        // 32x32 output block each: a unit's MFMAs (a chain over the K steps, started from
+        // zero) go into one of two partial tiles, and while they run the PREVIOUS unit's
+        // partial tile is scaled into the accumulators on the VALU -- the matrix pipe never
+        // waits for the scaling, and only two partial tiles exist (a second accumulator set
+        // would not fit 2 waves per SIMD).  The last unit of a K tile is retired under the
+        // first unit of the next one.
+        // The scales of the NEXT K tile are requested here and first read after the wait at
+        // the top of the next iteration: no memory wait inside the MFMA sequence.
+        float fa[TM];
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+        for (int j = 0; j < TM; ++j) fa[j] = sa_cur[j] * sb_cur;
+        if (kt + 1 < p.ktiles) {
 #pragma unroll
-          for (int j = 0; j < TM; ++j)
+          for (int j = 0; j < TM; ++j) sa_cur[j] = sa_row[j][(int64_t)(kt + 1) * p.sa_sk];
+          sb_cur = sb_col[(int64_t)(kt + 1) * p.sb_sk];
+        }
+        i32x8 xf[KSTEPS][TM];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) part[i][j][e] = 0.f;
-      }
-
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        // keep one K step's fragments live at a time (256-VGPR budget at 2 waves/SIMD)
-        if constexpr (DT == 1 && TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DT == 0) {
-          bf16x8 af[TN], bfr[TM];
-#pragma unroll
-          for (int i = 0; i < TN; ++i)
-            af[i] = *reinterpret_cast<const bf16x8*>(sbase + w_row_off + i * 32 * 128 + coff[s]);
-#pragma unroll
-          for (int j = 0; j < TM; ++j)
-            bfr[j] = *reinterpret_cast<const bf16x8*>(sbase + x_row_off + j * 32 * 128 + coff[s]);
-#pragma unroll
-          for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        } else {
-          i32x8 af[TN], bfr[TM];
-#pragma unroll
-          for (int i = 0; i < TN; ++i) {
-            const unsigned char* pa = sbase + w_row_off + i * 32 * 128;
-            i32x4 lo = *reinterpret_cast<const i32x4*>(pa + coff[s]);
-            i32x4 hi = *reinterpret_cast<const i32x4*>(pa + (coff[s] ^ 16));
-            af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          }
+        for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
             const unsigned char* pb = sbase + x_row_off + j * 32 * 128;
             i32x4 lo = *reinterpret_cast<const i32x4*>(pb + coff[s]);
             i32x4 hi = *reinterpret_cast<const i32x4*>(pb + (coff[s] ^ 16));
-            bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            xf[s][j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        i32x8 wf[KSTEPS];
+        auto load_w = [&](int i) {
+#pragma unroll
+          for (int s = 0; s < KSTEPS; ++s) {
+            const unsigned char* pa = sbase + w_row_off + i * 32 * 128;
+            i32x4 lo = *reinterpret_cast<const i32x4*>(pa + coff[s]);
+            i32x4 hi = *reinterpret_cast<const i32x4*>(pa + (coff[s] ^ 16));
+            wf[s] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        };
+        load_w(0);
+#pragma unroll
+        for (int u = 0; u < TN * TM; ++u) {
+          const int i = u / TM, j = u % TM;
+          {
+            f32x16 zero;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+            part[u & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                wf[0], xf[0][j], zero, 0, 0, 0, unit_scale, 0, unit_scale);
           }
 #pragma unroll
-          for (int i = 0; i < TN; ++i)
+          for (int s = 1; s < KSTEPS; ++s)
+            part[u & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                wf[s], xf[s][j], part[u & 1], 0, 0, 0, unit_scale, 0, unit_scale);
+          __builtin_amdgcn_sched_barrier(0);
+          if (j == TM - 1 && i + 1 < TN) load_w(i + 1);  // lands under the queued MFMAs
+          __builtin_amdgcn_sched_barrier(0);
+          if (u == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[TN - 1][TM - 1][e] += part[1][e] * pend_f;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              acc[(u - 1) / TM][(u - 1) % TM][e] += part[(u - 1) & 1][e] * fa[(u - 1) % TM];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        pend_f = fa[TM - 1];
+      } else {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          // keep one K step's fragments live at a time (256-VGPR budget at 2 waves/SIMD)
+          if constexpr (DT == 1 && TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);
+          if constexpr (DT == 0) {
+            bf16x8 af[TN], bfr[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+              af[i] = *reinterpret_cast<const bf16x8*>(sbase + w_row_off + i * 32 * 128 + coff[s]);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              bfr[j] = *reinterpret_cast<const bf16x8*>(sbase + x_row_off + j * 32 * 128 + coff[s]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+              for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          } else {
+            i32x8 af[TN], bfr[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+              const unsigned char* pa = sbase + w_row_off + i * 32 * 128;
+              i32x4 lo = *reinterpret_cast<const i32x4*>(pa + coff[s]);
+              i32x4 hi = *reinterpret_cast<const i32x4*>(pa + (coff[s] ^ 16));
+              af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-              if constexpr (BLOCKSCALE) {
-                part[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                    af[i], bfr[j], part[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
-              } else {
+              const unsigned char* pb = sbase + x_row_off + j * 32 * 128;
+              i32x4 lo = *reinterpret_cast<const i32x4*>(pb + coff[s]);
+              i32x4 hi = *reinterpret_cast<const i32x4*>(pb + (coff[s] ^ 16));
+              bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+              for (int j = 0; j < TM; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
                     af[i], bfr[j], acc[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
-              }
-            }
-        }
-      }
-      if constexpr (BLOCKSCALE) {
-        // one K tile == one 128-wide scale block
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          int nb = (n0 + wn * TN * 32 + i * 32) >> 7;
-          const int nb_max = (p.N - 1) >> 7;
-          if (nb > nb_max) nb = nb_max;
-          const float sbv = p.sb[kt * p.sb_sk + nb * p.sb_sn];
-#pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            const float f = sa_row[j][kt * p.sa_sk] * sbv;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] += part[i][j][e] * f;
           }
         }
       }
+    }
+
+    if constexpr (BLOCKSCALE) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[TN - 1][TM - 1][e] += part[1][e] * pend_f;
     }
 
     // ---- tile done: park the tables, prefetch the next tile, run the epilogue ----------
@@ -598,11 +660,12 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
     p.sa_sk = a->sa_sk;
     p.sb_sk = a->sb_sk;
     p.sb_sn = a->sb_sn;
-    return launch_gemm<1, 2, 2, 2, 2, true>(p, st);
   }
   // Tile choice: 256x256 (8 waves) when the grid still covers the chip, else 128x128.
   const int64_t big_tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
   const bool big = big_tiles >= 192;
+  if (a->block_scale)
+    return big ? launch_gemm<1, 4, 2, 2, 4, true>(p, st) : launch_gemm<1, 2, 2, 2, 2, true>(p, st);
   if (a->fp8) {
     return big ? launch_gemm<1, 4, 2, 2, 4, false>(p, st) : launch_gemm<1, 2, 2, 2, 2, false>(p, st);
   }

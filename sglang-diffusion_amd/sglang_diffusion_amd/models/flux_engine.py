@@ -191,7 +191,7 @@ class FluxEngine:
     def _lin(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
              gate=None, gate_rows=0, act=0, ldo=None, lda=None, f16_cols=None):
         # same tile rule as csrc/gemm.hip: the 256x256 kernel when it yields >= 192 tiles
-        big = ((M + 255) // 256) * ((pk.N + 255) // 256) >= 192 and not pk.block
+        big = ((M + 255) // 256) * ((pk.N + 255) // 256) >= 192
         self._run(("gemm_fp8blk" if pk.block else "gemm_fp8" if pk.fp8 else "gemm_bf16")
                   + ("_256" if big else "_128"),
                   2.0 * M * pk.N * pk.K,

@@ -1,13 +1,20 @@
-"""Times the linear kernels on the Flux shapes (random data).  python tools/gemm_probe.py [fp8|bf16]"""
+"""Times the linear kernels on the Flux shapes (random data).
+python tools/gemm_probe.py [fp8|bf16|block|both]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sglang-diffusion_amd"))
 import torch
 from sglang_diffusion_amd import _C
 
-def bench(fp8, M, N, K, iters=20, **kw):
+def bench(fp8, M, N, K, iters=20, block=False, **kw):
     dev = "cuda"
-    if fp8:
+    if block:
+        a = (torch.randn(M, K, device=dev) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
+        w = (torch.randn(N, K, device=dev) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
+        sa = torch.rand(M, K // 128, device=dev) * 0.01
+        sb = torch.rand((N + 127) // 128, K // 128, device=dev) * 0.01
+        kw["block_scale"] = True
+    elif fp8:
         a = (torch.randn(M, K, device=dev) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
         w = (torch.randn(N, K, device=dev) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
         sa = torch.rand(M, device=dev) * 0.01; sb = torch.rand(N, device=dev) * 0.01
@@ -24,13 +31,17 @@ def bench(fp8, M, N, K, iters=20, **kw):
     for _ in range(iters): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
-    print(f"{'fp8' if fp8 else 'bf16'} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s", flush=True)
+    print(f"{'fp8-block' if block else 'fp8' if fp8 else 'bf16'} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s", flush=True)
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "both"
 print("MI355_GEMM_DBG =", os.environ.get("MI355_GEMM_DBG"))
 if mode in ("fp8", "both"):
     for (M, N, K) in [(16384, 9216, 3072), (18432, 12288, 3072), (18432, 3072, 15360), (8192, 8192, 8192)]:
         bench(True, M, N, K)
+if mode == "block":
+    for (M, N, K) in [(16384, 9216, 3072), (18432, 12288, 3072), (18432, 3072, 15360), (8192, 8192, 8192),
+                      (18432, 3072, 3072), (2048, 9216, 3072)]:
+        bench(True, M, N, K, block=True)
 if mode in ("bf16", "both"):
     for (M, N, K) in [(16384, 12288, 3072), (16384, 3072, 12288), (8192, 8192, 8192)]:
         bench(False, M, N, K)
