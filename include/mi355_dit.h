@@ -37,7 +37,7 @@ const char* mi355_last_error(void);
 /* 2: mi355_linear_args gained f16_begin/f16_end; mi355_flash_attn_fwd_f16v and
  *    mi355_bf16_to_f16 were added.
  * 3: mi355_linear_args gained block_scale and the four scale strides;
- *    mi355_layernorm_modulate_group_quant was added. */
+ *    mi355_layernorm_modulate_group_quant and mi355_merge_attn_states were added. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -292,6 +292,23 @@ int mi355_euler_step(void* out, const void* sample, const void* v, float sigma,
  *   out = bf16(u + bf16(s * bf16(c - u))). */
 int mi355_cfg_combine(void* out, const void* cond, const void* uncond, float scale,
                       int64_t n, void* stream);
+
+/* Merge of two partial attention results over disjoint key sets (ring / context-parallel
+ * attention): out = (a e^(la-m) + b e^(lb-m)) / (e^(la-m) + e^(lb-m)), lse = log(sum) + m,
+ * m = max(la, lb); an infinite log-sum-exp marks an empty side.
+ *   merge_state_v2(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor! v_merged,
+ *                  Tensor! s_merged)   (sgl-kernel/csrc/common_extension.cc:55-56,
+ *                  sgl-kernel/csrc/attention/merge_attn_states.cu:31-109,180-204)
+ * out/a/b bf16 [B, S, H, D] and the fp32 log-sum-exps [B, S, H], each addressed through three
+ * element strides {batch, token, head} (last dimension of out/a/b contiguous), so both the
+ * op's [tokens, heads] layout and mi355_flash_attn_fwd's [B, H, S] layout fit.  out may alias
+ * a or b; out_lse (and out_lse_strides) may be NULL.  D % 8 == 0. */
+int mi355_merge_attn_states(void* out, float* out_lse, const void* a, const float* a_lse,
+                            const void* b, const float* b_lse, int64_t B, int64_t S, int64_t H,
+                            int64_t D, const int64_t* out_strides, const int64_t* a_strides,
+                            const int64_t* b_strides, const int64_t* out_lse_strides,
+                            const int64_t* a_lse_strides, const int64_t* b_lse_strides,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -194,6 +194,19 @@ def attention(q, k, v, scale: Optional[float] = None, return_lse: bool = False):
     return o
 
 
+def merge_attn_states(v_a, s_a, v_b, s_b):
+    """sgl-kernel/csrc/attention/merge_attn_states.cu:31-109 (the formula its test restates,
+    sgl-kernel/tests/test_merge_state_v2.py:11-62): v [tokens, heads, D] in the output dtype,
+    s [tokens, heads] fp32 log-sum-exps; +inf counts as -inf.  Returns (v_merged, s_merged)."""
+    la = torch.where(torch.isinf(s_a), torch.full_like(s_a, float("-inf")), s_a.float())
+    lb = torch.where(torch.isinf(s_b), torch.full_like(s_b, float("-inf")), s_b.float())
+    m = torch.maximum(la, lb)
+    wa, wb = torch.exp(la - m), torch.exp(lb - m)
+    tot = wa + wb
+    out = v_a.float() * (wa / tot).unsqueeze(-1) + v_b.float() * (wb / tot).unsqueeze(-1)
+    return out.to(v_a.dtype), torch.log(tot) + m
+
+
 # --------------------------------------------------------------- norm / rope --
 def rmsnorm(x, w, eps: float):
     """RMSNorm.forward_native (python/sglang/multimodal_gen/runtime/layers/layernorm.py:106-143)."""

@@ -802,3 +802,98 @@ extern "C" int mi355_bf16_to_f16(const void* x, void* y, int64_t rows, int64_t c
   MI355_CHECK_LAUNCH("bf16_to_f16");
   return MI355_OK;
 }
+
+// ---------------------------------------------------- merge of attention states ----
+// Two partial attention results over disjoint key sets, each normalised by its own softmax
+// sum, and their log-sum-exps -> the result over the union
+// (sgl-kernel/csrc/attention/merge_attn_states.cu:31-109):
+//   m = max(la, lb); wa = e^(la-m), wb = e^(lb-m); out = (a wa + b wb) / (wa + wb);
+//   lse = log(wa + wb) + m.   +inf log-sum-exps count as -inf (an empty side).
+// One thread per 16 bytes of a head row; tensors [B, S, H, D] and [B, S, H] by strides.
+namespace {
+struct MergeParams {
+  unsigned short* o;
+  float* o_lse;
+  const unsigned short* a;
+  const float* a_lse;
+  const unsigned short* b;
+  const float* b_lse;
+  int64_t B, S, H;
+  int vec;  // D / 8
+  int64_t o_sb, o_ss, o_sh, a_sb, a_ss, a_sh, b_sb, b_ss, b_sh;
+  int64_t ol_sb, ol_ss, ol_sh, al_sb, al_ss, al_sh, bl_sb, bl_ss, bl_sh;
+};
+
+__global__ __launch_bounds__(256) void merge_attn_states_kernel(MergeParams p) {
+  const int64_t total = p.B * p.S * p.H * p.vec;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % p.vec);
+    int64_t t = idx / p.vec;
+    const int64_t h = t % p.H;
+    t /= p.H;
+    const int64_t s = t % p.S, bb = t / p.S;
+    float la = p.a_lse[bb * p.al_sb + s * p.al_ss + h * p.al_sh];
+    float lb = p.b_lse[bb * p.bl_sb + s * p.bl_ss + h * p.bl_sh];
+    if (isinf(la)) la = -INFINITY;
+    if (isinf(lb)) lb = -INFINITY;
+    const float m = fmaxf(la, lb);
+    const float wa = expf(la - m), wb = expf(lb - m);
+    const float sum = wa + wb;
+    const float fa = wa / sum, fb = wb / sum;
+    const u32x4 av = *reinterpret_cast<const u32x4*>(p.a + bb * p.a_sb + s * p.a_ss + h * p.a_sh + 8 * v);
+    const u32x4 bv = *reinterpret_cast<const u32x4*>(p.b + bb * p.b_sb + s * p.b_ss + h * p.b_sh + 8 * v);
+    u32x4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a0 = __uint_as_float(av[e] << 16), a1 = __uint_as_float(av[e] & 0xffff0000u);
+      const float b0 = __uint_as_float(bv[e] << 16), b1 = __uint_as_float(bv[e] & 0xffff0000u);
+      ov[e] = pack_bf2(fmaf(a0, fa, __fmul_rn(b0, fb)), fmaf(a1, fa, __fmul_rn(b1, fb)));
+    }
+    *reinterpret_cast<u32x4*>(p.o + bb * p.o_sb + s * p.o_ss + h * p.o_sh + 8 * v) = ov;
+    if (p.o_lse && v == 0) p.o_lse[bb * p.ol_sb + s * p.ol_ss + h * p.ol_sh] = logf(sum) + m;
+  }
+}
+}  // namespace
+
+extern "C" int mi355_merge_attn_states(void* out, float* out_lse, const void* a, const float* a_lse,
+                                       const void* b, const float* b_lse, int64_t B, int64_t S,
+                                       int64_t H, int64_t D, const int64_t* out_strides,
+                                       const int64_t* a_strides, const int64_t* b_strides,
+                                       const int64_t* out_lse_strides, const int64_t* a_lse_strides,
+                                       const int64_t* b_lse_strides, void* stream) {
+  MI355_REQUIRE(B >= 0 && S >= 0 && H > 0 && D > 0 && D % 8 == 0,
+                "merge_attn_states: bad shape B=%ld S=%ld H=%ld D=%ld", (long)B, (long)S, (long)H,
+                (long)D);
+  if (B == 0 || S == 0) return MI355_OK;
+  MI355_REQUIRE(out && a && a_lse && b && b_lse && out_strides && a_strides && b_strides &&
+                    a_lse_strides && b_lse_strides && (!out_lse || out_lse_strides),
+                "merge_attn_states: null pointer");
+  MI355_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0,
+                "merge_attn_states: tensors must be 16-byte aligned");
+  for (int i = 0; i < 3; ++i)
+    MI355_REQUIRE(out_strides[i] % 8 == 0 && a_strides[i] % 8 == 0 && b_strides[i] % 8 == 0,
+                  "merge_attn_states: strides must be multiples of 8 elements");
+  MergeParams p;
+  p.o = (unsigned short*)out;
+  p.o_lse = out_lse;
+  p.a = (const unsigned short*)a;
+  p.a_lse = a_lse;
+  p.b = (const unsigned short*)b;
+  p.b_lse = b_lse;
+  p.B = B; p.S = S; p.H = H;
+  p.vec = (int)(D / 8);
+  p.o_sb = out_strides[0]; p.o_ss = out_strides[1]; p.o_sh = out_strides[2];
+  p.a_sb = a_strides[0]; p.a_ss = a_strides[1]; p.a_sh = a_strides[2];
+  p.b_sb = b_strides[0]; p.b_ss = b_strides[1]; p.b_sh = b_strides[2];
+  p.ol_sb = out_lse ? out_lse_strides[0] : 0;
+  p.ol_ss = out_lse ? out_lse_strides[1] : 0;
+  p.ol_sh = out_lse ? out_lse_strides[2] : 0;
+  p.al_sb = a_lse_strides[0]; p.al_ss = a_lse_strides[1]; p.al_sh = a_lse_strides[2];
+  p.bl_sb = b_lse_strides[0]; p.bl_ss = b_lse_strides[1]; p.bl_sh = b_lse_strides[2];
+  const int64_t total = B * S * H * p.vec;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(merge_attn_states_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  MI355_CHECK_LAUNCH("merge_attn_states");
+  return MI355_OK;
+}

@@ -47,6 +47,9 @@ SCHEMAS = {
                                         "Tensor cos_sin_cache, Tensor pos_ids, bool interleave, "
                                         "bool enable_pdl, Tensor? v, Tensor!? k_buffer, "
                                         "Tensor!? v_buffer, Tensor? kv_cache_loc) -> ()",
+    # sgl-kernel/csrc/common_extension.cc:55-56
+    "merge_state_v2": "(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor! v_merged, "
+                      "Tensor! s_merged) -> ()",
     # sgl-kernel/csrc/flash_extension.cc:25-63
     "fwd": "(Tensor q, Tensor k, Tensor v, Tensor? k_new, Tensor? v_new, Tensor? q_v, "
            "Tensor? out, Tensor? cu_seqlens_q, Tensor? cu_seqlens_k, Tensor? cu_seqlens_k_new, "
@@ -277,7 +280,24 @@ def _fwd(q, k, v, k_new, v_new, q_v, out, cu_seqlens_q, cu_seqlens_k, cu_seqlens
     return out, lse, empty, empty
 
 
+def _merge_state_v2(v_a, s_a, v_b, s_b, v_merged, s_merged):
+    """sgl-kernel/csrc/attention/merge_attn_states.cu:180-204: contiguous [tokens, heads, D] /
+    [tokens, heads] operands on one device."""
+    for t in (v_a, s_a, v_b, s_b, v_merged, s_merged):
+        _require(t.is_cuda and t.is_contiguous(), "merge_state_v2: contiguous device tensors expected")
+    _require(v_a.dim() == 3 and s_a.dim() == 2 and v_b.shape == v_a.shape and s_b.shape == s_a.shape
+             and v_merged.shape == v_a.shape and s_merged.shape == s_a.shape
+             and s_a.shape == v_a.shape[:2], "merge_state_v2: shape mismatch")
+    _require(v_merged.dtype == torch.bfloat16 and v_a.dtype == torch.bfloat16
+             and v_b.dtype == torch.bfloat16, "merge_state_v2: bfloat16 states only")
+    _require(s_a.dtype == torch.float32 and s_b.dtype == torch.float32
+             and s_merged.dtype == torch.float32, "merge_state_v2: float32 log-sum-exps only")
+    _C.merge_attn_states(v_merged.unsqueeze(0), s_merged.unsqueeze(0), v_a.unsqueeze(0),
+                         s_a.unsqueeze(0), v_b.unsqueeze(0), s_b.unsqueeze(0), lse_layout="bsh")
+
+
 _IMPLS = {
+    "merge_state_v2": _merge_state_v2,
     "fp8_scaled_mm": _fp8_scaled_mm,
     "fp8_blockwise_scaled_mm": _fp8_blockwise_scaled_mm,
     "sgl_per_token_quant_fp8": _sgl_per_token_quant_fp8,
@@ -309,7 +329,8 @@ def _fake_none(*args, **kwargs):
 
 
 for _name in ("sgl_per_token_quant_fp8", "sgl_per_token_group_quant_8bit", "sgl_per_tensor_quant_fp8",
-              "rmsnorm", "fused_add_rmsnorm", "rotary_embedding", "apply_rope_pos_ids_cos_sin_cache"):
+              "rmsnorm", "fused_add_rmsnorm", "rotary_embedding", "apply_rope_pos_ids_cos_sin_cache",
+              "merge_state_v2"):
     torch.library.register_fake("sgl_kernel::" + _name)(_fake_none)
 
 

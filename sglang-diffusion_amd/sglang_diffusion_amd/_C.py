@@ -105,6 +105,10 @@ SIGNATURES = {
         _int,
         [_ptr] * 5 + [_i64] * 5 + [_f32, ctypes.POINTER(RowMap), _ptr],
     ),
+    "mi355_merge_attn_states": (
+        _int,
+        [_ptr] * 6 + [_i64] * 4 + [ctypes.POINTER(_i64)] * 6 + [_ptr],
+    ),
     "mi355_gate_residual": (
         _int,
         [_ptr] * 4 + [_i64] * 7 + [ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), _ptr],
@@ -279,6 +283,39 @@ def flash_attn_fwd(q, k, v, out, lse, softmax_scale: float, causal: bool = False
             float(softmax_scale), int(bool(causal)), _stream(q),
         ),
         "flash_attn_fwd",
+    )
+
+
+def merge_attn_states(out, out_lse, a, a_lse, b, b_lse, lse_layout: str = "bhs") -> None:
+    """out/a/b: bf16 [B, S, H, D] (last dimension contiguous); log-sum-exps fp32, [B, H, S] as
+    flash_attn_fwd writes them (lse_layout "bhs") or [B, S, H] ("bsh").  out may alias a or b;
+    out_lse may be None."""
+    B, S, H, D = a.shape
+    for t in (out, a, b):
+        if t.shape != a.shape or t.stride(-1) != 1 or t.dtype != torch.bfloat16:
+            raise RuntimeError("merge_attn_states: bf16 [B,S,H,D] tensors of one shape expected")
+    if lse_layout not in ("bhs", "bsh"):
+        raise ValueError("lse_layout must be 'bhs' or 'bsh'")
+
+    def st3(t):
+        return (_i64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+    def lse3(t):
+        want = (B, H, S) if lse_layout == "bhs" else (B, S, H)
+        if tuple(t.shape) != want or t.dtype != torch.float32:
+            raise RuntimeError(f"merge_attn_states: fp32 log-sum-exp of shape {want} expected, "
+                               f"got {tuple(t.shape)} {t.dtype}")
+        if lse_layout == "bhs":
+            return (_i64 * 3)(t.stride(0), t.stride(2), t.stride(1))
+        return (_i64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+    _check(
+        load_library().mi355_merge_attn_states(
+            out.data_ptr(), _p(out_lse), a.data_ptr(), a_lse.data_ptr(), b.data_ptr(),
+            b_lse.data_ptr(), B, S, H, D, st3(out), st3(a), st3(b),
+            lse3(out_lse) if out_lse is not None else None, lse3(a_lse), lse3(b_lse), _stream(a),
+        ),
+        "merge_attn_states",
     )
 
 

@@ -4,7 +4,8 @@ Replaces the slice of python/sglang/multimodal_gen/runtime/distributed/parallel_
 the DiT path needs.  Flux scales by DATA parallelism over the CFG x request batch: requests are
 independent, so there is no collective inside a denoise step, only a scatter of the work list
 and a gather of the final latents.  Ulysses all-to-all (layers/usp.py:49-158) is provided for the
-sequence-parallel attention wrapper.
+sequence-parallel attention wrapper, and ring attention (layers/usp.py:161-252) for sequences
+that are sharded over the keys as well.
 """
 from __future__ import annotations
 
@@ -68,3 +69,67 @@ def ulysses_all_to_all(x: torch.Tensor, group, scatter_dim: int, gather_dim: int
     recv = torch.empty_like(parts)
     dist.all_to_all_single(recv, parts, group=group)
     return torch.cat(list(recv.unbind(0)), dim=gather_dim)
+
+
+def _hip_attention(q, k, v, scale):
+    from .. import _C
+
+    B, S, H, D = q.shape
+    out = torch.empty_like(q)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    _C.attention(q, k, v, out, lse, scale)
+    return out, lse
+
+
+def _hip_merge(out, lse, a, a_lse, b, b_lse):
+    from .. import _C
+
+    _C.merge_attn_states(out, lse, a, a_lse, b, b_lse, lse_layout="bhs")
+
+
+def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group=None,
+                   softmax_scale: Optional[float] = None, is_causal: bool = False,
+                   attn_fn=None, merge_fn=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dense attention of the local queries over the keys of EVERY rank of `group`
+    (layers/usp.py:161-252, which drives torch's _templated_ring_attention).
+
+    q, k, v: this rank's shards [B, S_local, H, D] (bf16).  In step s the rank attends to the
+    K/V shard that started on rank (r - s) mod P while that shard is already on its way to rank
+    r + 1 (point-to-point isend/irecv: one xGMI link per direction, overlapped with the
+    attention kernel), and folds the partial result into the running one with its
+    log-sum-exp (mi355_merge_attn_states).  The layout stays [B, S, H, D] throughout: the
+    kernels take strides, so the reference's [B, H, S, D] permutes have no counterpart.
+    Returns (out [B, S_local, H, D], lse [B, H, S_local]).
+
+    attn_fn(q, k, v, scale) -> (out, lse [B, H, S]) and merge_fn(out, lse, a, a_lse, b, b_lse)
+    default to the HIP kernels; the multi-process CPU tests pass reference callables."""
+    if is_causal:
+        raise NotImplementedError("ring attention: causal masking is not built (the DiT path is dense)")
+    attn_fn = attn_fn or _hip_attention
+    merge_fn = merge_fn or _hip_merge
+    scale = softmax_scale if softmax_scale is not None else q.shape[-1] ** -0.5
+    P = dist.get_world_size(group) if dist.is_initialized() else 1
+    if P == 1:
+        return attn_fn(q, k, v, scale)
+    rank = dist.get_rank(group)
+    nxt = dist.get_global_rank(group, (rank + 1) % P) if group is not None else (rank + 1) % P
+    prv = dist.get_global_rank(group, (rank - 1) % P) if group is not None else (rank - 1) % P
+    k_cur, v_cur = k.contiguous(), v.contiguous()
+    out = lse = None
+    for step in range(P):
+        reqs = []
+        if step + 1 < P:
+            k_nxt, v_nxt = torch.empty_like(k_cur), torch.empty_like(v_cur)
+            ops = [dist.P2POp(dist.isend, k_cur, nxt, group), dist.P2POp(dist.isend, v_cur, nxt, group),
+                   dist.P2POp(dist.irecv, k_nxt, prv, group), dist.P2POp(dist.irecv, v_nxt, prv, group)]
+            reqs = dist.batch_isend_irecv(ops)
+        o_s, lse_s = attn_fn(q, k_cur, v_cur, scale)
+        if out is None:
+            out, lse = o_s, lse_s
+        else:
+            merge_fn(out, lse, out, lse, o_s, lse_s)
+        for r in reqs:
+            r.wait()
+        if step + 1 < P:
+            k_cur, v_cur = k_nxt, v_nxt
+    return out, lse

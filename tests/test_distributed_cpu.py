@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from sglang_diffusion_amd.runtime.batch_scheduler import DataParallelBatchScheduler, merge_requests
-from sglang_diffusion_amd.runtime.parallel import (gather_latents, init_distributed, shard_requests,
+from sglang_diffusion_amd.runtime.parallel import (gather_latents, init_distributed, ring_attention,
+                                                   shard_requests,
                                                    ulysses_all_to_all)
 from sglang_diffusion_amd.runtime.synthetic import make_synthetic_request
 
@@ -115,3 +116,48 @@ def test_dp_scheduler_two_ranks_equals_serial():
     assert ret[1][1] is None
     expect = torch.cat([_FakeStage().forward(merge_requests([r])).latents for r in _queue()], dim=0)
     assert torch.equal(ret[0][1], expect.float())
+
+
+def _ring_case(rank):
+    """Two ranks, queries and keys both sharded along the sequence: the ring result for the
+    local queries equals dense attention over the concatenated keys.  The per-step attention
+    and the merge are the CPU oracle's (the HIP kernels are the default on a GPU)."""
+    from oracle import ops as O
+
+    B, S, H, D = 2, 24, 3, 16
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(B, S, H, D, generator=g).bfloat16()
+    k = torch.randn(B, S, H, D, generator=g).bfloat16()
+    v = torch.randn(B, S, H, D, generator=g).bfloat16()
+    sl = slice(rank * S // WORLD, (rank + 1) * S // WORLD)
+
+    def attn(q_, k_, v_, scale):
+        return O.attention(q_, k_, v_, scale, return_lse=True)
+
+    def merge(out, lse, a, a_lse, b, b_lse):
+        # oracle layout: [tokens, heads, D] and [tokens, heads]
+        Bq, Sq = a.shape[:2]
+        vm, sm = O.merge_attn_states(a.reshape(Bq * Sq, H, D), a_lse.transpose(1, 2).reshape(Bq * Sq, H),
+                                     b.reshape(Bq * Sq, H, D), b_lse.transpose(1, 2).reshape(Bq * Sq, H))
+        out.copy_(vm.view(Bq, Sq, H, D))
+        lse.copy_(sm.view(Bq, Sq, H).transpose(1, 2))
+
+    out, lse = ring_attention(q[:, sl].contiguous(), k[:, sl].contiguous(), v[:, sl].contiguous(),
+                              dist.group.WORLD, attn_fn=attn, merge_fn=merge)
+    ref, ref_lse = O.attention(q[:, sl], k, v, D ** -0.5, return_lse=True)
+    err = (out.float() - ref.float()).norm() / ref.float().norm()
+    lse_err = (lse - ref_lse).abs().max()
+    try:
+        ring_attention(q, k, v, dist.group.WORLD, is_causal=True, attn_fn=attn, merge_fn=merge)
+        raised = False
+    except NotImplementedError:
+        raised = True
+    return float(err), float(lse_err), raised
+
+
+def test_ring_attention_two_ranks_equals_dense():
+    ret = _run(_ring_case)
+    for rank in range(WORLD):
+        err, lse_err, raised = ret[rank]
+        # one extra bf16 rounding of the partial results before the merge
+        assert err <= 6e-3 and lse_err <= 1e-5 and raised, ret[rank]

@@ -407,6 +407,50 @@ def test_linear_ex_half_output_columns(device, fp8):
         _C.linear_ex(a_d, w_d, mixed, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, f16_cols=(250, 384), **kw)
 
 
+@pytest.mark.parametrize("T,H,D", [(37, 3, 128), (512, 24, 128), (5, 2, 64)])
+def test_merge_attn_states_vs_oracle(device, T, H, D):
+    """merge_state_v2 (sgl-kernel/tests/test_merge_state_v2.py): contiguous [tokens, heads, D],
+    with empty sides (+-inf log-sum-exps) mixed in."""
+    import sgl_kernel
+
+    va = torch.randn(T, H, D, generator=g(81)).bfloat16()
+    vb = torch.randn(T, H, D, generator=g(82)).bfloat16()
+    sa = torch.randn(T, H, generator=g(83)) * 3
+    sb = torch.randn(T, H, generator=g(84)) * 3
+    sa[0, 0] = float("inf")       # treated as -inf: an empty side
+    sb[1 % T, 0] = float("-inf")
+    ref_v, ref_s = ops.merge_attn_states(va, sa, vb, sb)
+    got_v, got_s = sgl_kernel.merge_state_v2(va.to(device), sa.to(device), vb.to(device), sb.to(device))
+    assert bf16_ulp_diff(got_v, ref_v).max() <= 1          # fma vs mul+add in fp32
+    assert torch.allclose(got_s.cpu(), ref_s, rtol=1e-6, atol=1e-6)
+    assert torch.equal(got_v[0, 0].cpu(), vb[0, 0]) and torch.equal(got_v[1 % T, 0].cpu(), va[1 % T, 0])
+    with pytest.raises(RuntimeError):
+        sgl_kernel.merge_state_v2(va.to(device)[:, :, ::2], sa.to(device), vb.to(device), sb.to(device))
+
+
+def test_attention_over_key_halves_merges_to_the_whole(device):
+    """Size-independent property at the Flux shape of one sample: attention over the first and
+    the second half of the keys, merged with their log-sum-exps (strided [B, H, S] layout, in
+    place), equals attention over all keys up to the extra bf16 rounding of the two partials."""
+    B, S, H, D = 1, 4608, 24, 128
+    qkv = (torch.randn(B, S, 3, H, D, generator=g(91)) * 1.5).bfloat16().to(device)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    scale = D ** -0.5
+    whole = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=device)
+    lse_w = torch.empty(B, H, S, dtype=torch.float32, device=device)
+    _C.attention(q, k, v, whole, lse_w, scale)
+    parts = []
+    for sl in (slice(0, 2000), slice(2000, S)):      # ragged split, second half not tile aligned
+        o = torch.empty_like(whole)
+        l = torch.empty_like(lse_w)
+        _C.attention(q, k[:, sl], v[:, sl], o, l, scale)
+        parts.append((o, l))
+    (oa, la), (ob, lb) = parts
+    _C.merge_attn_states(oa, la, oa, la, ob, lb)      # in place over the first partial
+    assert rel_l2(oa, whole) <= 3e-3
+    assert (la - lse_w).abs().max().item() <= 2e-5
+
+
 # ------------------------------------------------------------------------- norm / rope --
 @pytest.mark.parametrize("rows,dim,wf32", [(37, 128, True), (5, 3072, False), (1000, 128, True)])
 def test_rmsnorm_vs_oracle(device, rows, dim, wf32):
