@@ -272,3 +272,71 @@ class USPAttention(nn.Module):
         v = ulysses_all_to_all(v, group, scatter_dim=2, gather_dim=1)
         out = self.attn_impl.forward(q, k, v, md)
         return ulysses_all_to_all(out, group, scatter_dim=1, gather_dim=2)
+
+
+class UlyssesAttention(nn.Module):
+    """layer.py:38-154: sequence-parallel attention with an optional REPLICATED token set.
+
+    q, k, v hold this rank's slice of the main (image / video) sequence with all heads; the
+    exchange turns them into the whole sequence with H / P heads.  The replicated tokens (text)
+    are present on every rank with all heads: each rank takes its own H / P heads of them
+    locally, appends them BEHIND the main sequence, runs the kernel once, and the text part of
+    the result is all-gathered over heads.  q, k and v travel stacked in ONE all-to-all
+    (three tensors, one message per peer) instead of the reference's cat along the batch.
+
+    `attn_impl` may be given for tests without a GPU; the default is the HIP backend."""
+
+    def __init__(self, num_heads: int, head_size: int, num_kv_heads: int | None = None,
+                 softmax_scale: float | None = None, causal: bool = False,
+                 supported_attention_backends=None, prefix: str = "", group=None,
+                 attn_impl=None, **extra_impl_args) -> None:
+        super().__init__()
+        self.softmax_scale = head_size ** -0.5 if softmax_scale is None else softmax_scale
+        num_kv_heads = num_kv_heads or num_heads
+        if attn_impl is None:
+            backend = get_attn_backend(head_size, torch.bfloat16, supported_attention_backends)
+            attn_impl = backend.get_impl_cls()(num_heads=num_heads, head_size=head_size,
+                                               causal=causal, softmax_scale=self.softmax_scale,
+                                               num_kv_heads=num_kv_heads, prefix=f"{prefix}.impl",
+                                               **extra_impl_args)
+            self.backend = backend.get_enum()
+        self.attn_impl = attn_impl
+        self.num_heads, self.head_size, self.num_kv_heads = num_heads, head_size, num_kv_heads
+        self.group = group
+
+    def forward(self, q, k, v, replicated_q=None, replicated_k=None, replicated_v=None):
+        assert q.dim() == 4 and k.dim() == 4 and v.dim() == 4, "Expected 4D tensors"
+        import torch.distributed as dist
+
+        from ..runtime.parallel import ulysses_all_to_all
+
+        B, S, H, D = q.shape
+        group = self.group
+        P = dist.get_world_size(group) if (group is not None and dist.is_initialized()) else 1
+        rank = dist.get_rank(group) if P > 1 else 0
+        md = get_forward_context().attn_metadata
+        if P > 1:
+            if H % P:
+                raise ValueError(f"{H} heads do not divide over {P} ranks")
+            qkv = ulysses_all_to_all(torch.cat([q, k, v], dim=0), group, scatter_dim=2, gather_dim=1)
+            q, k, v = qkv.chunk(3, dim=0)
+        n_main = q.shape[1]
+        if replicated_q is not None:
+            assert replicated_k is not None and replicated_v is not None
+            hp = H // P
+            hs = slice(rank * hp, (rank + 1) * hp)
+            q = torch.cat([q, replicated_q[:, :, hs]], dim=1)
+            k = torch.cat([k, replicated_k[:, :, hs]], dim=1)
+            v = torch.cat([v, replicated_v[:, :, hs]], dim=1)
+        out = self.attn_impl.forward(q, k, v, md)
+        rep_out = None
+        if replicated_q is not None:
+            rep_out = out[:, n_main:]
+            out = out[:, :n_main]
+            if P > 1:
+                parts = [torch.empty_like(rep_out) for _ in range(P)]
+                dist.all_gather(parts, rep_out.contiguous(), group=group)
+                rep_out = torch.cat(parts, dim=2)
+        if P > 1:
+            out = ulysses_all_to_all(out.contiguous(), group, scatter_dim=1, gather_dim=2)
+        return out, rep_out

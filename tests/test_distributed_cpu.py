@@ -161,3 +161,40 @@ def test_ring_attention_two_ranks_equals_dense():
         err, lse_err, raised = ret[rank]
         # one extra bf16 rounding of the partial results before the merge
         assert err <= 6e-3 and lse_err <= 1e-5 and raised, ret[rank]
+
+
+class _OracleImpl:
+    """Attention implementation stand-in for the CPU: the oracle's dense attention."""
+
+    def forward(self, q, k, v, attn_metadata=None):
+        from oracle import ops as O
+
+        return O.attention(q, k, v)
+
+
+def _ulysses_replicated_case(rank):
+    """UlyssesAttention with a replicated text part (layers/attention/layer.py:84-152): the
+    video tokens are sharded over the ranks, the text tokens are on both; the result equals one
+    dense attention over [video | text] on a single rank."""
+    from oracle import ops as O
+    from sglang_diffusion_amd.layers.attention import UlyssesAttention
+    from sglang_diffusion_amd.layers.forward_context import set_forward_context
+
+    B, S, T, H, D = 1, 16, 6, 4, 16
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(3, B, S, H, D, generator=g).bfloat16()
+    tqkv = torch.randn(3, B, T, H, D, generator=g).bfloat16()
+    sl = slice(rank * S // WORLD, (rank + 1) * S // WORLD)
+    layer = UlyssesAttention(H, D, group=dist.group.WORLD, attn_impl=_OracleImpl())
+    with set_forward_context(current_timestep=0, attn_metadata=None):
+        out, rep = layer(qkv[0][:, sl].contiguous(), qkv[1][:, sl].contiguous(),
+                         qkv[2][:, sl].contiguous(), tqkv[0], tqkv[1], tqkv[2])
+    ref = O.attention(torch.cat([qkv[0], tqkv[0]], 1), torch.cat([qkv[1], tqkv[1]], 1),
+                      torch.cat([qkv[2], tqkv[2]], 1))
+    return torch.equal(out, ref[:, sl]), torch.equal(rep, ref[:, S:])
+
+
+def test_ulysses_attention_with_replicated_text():
+    ret = _run(_ulysses_replicated_case)
+    for rank in range(WORLD):
+        assert ret[rank] == (True, True), ret[rank]

@@ -1,0 +1,84 @@
+"""HunyuanVideo MM-DiT blocks (sequence-parallel configuration's model) on the HIP kernels
+against the CPU oracle's restatement of the reference's eager path.  Parity is UNPINNED for
+these blocks (see oracle/hunyuan_oracle.py): both sides restate the same reading of the
+reference; the operators underneath are the ones pinned on the Flux path."""
+import pytest
+import torch
+
+from oracle.hunyuan_oracle import HunyuanBlocksOracle
+from sglang_diffusion_amd.layers.quantization import Fp8Config
+from sglang_diffusion_amd.models.hunyuanvideo import (MMDoubleStreamBlock, MMSingleStreamBlock,
+                                                      process_weights_after_loading)
+from sglang_diffusion_amd.runtime.synthetic import init_synthetic_weights
+from tests.helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+HID, HEADS = 256, 2      # head size 128, as HunyuanVideo (3072 / 24)
+
+
+def _inputs(B, Ti, Tt, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, Ti, HID, generator=g).bfloat16()
+    txt = (torch.randn(B, Tt, HID, generator=g) * 0.5).bfloat16()
+    vec = torch.randn(B, HID, generator=g).bfloat16()
+    ang = torch.rand(Ti, HID // HEADS // 2, generator=g) * 6.28
+    return img, txt, vec, torch.cos(ang), torch.sin(ang)
+
+
+def _build(cls, device, fp8, prefix):
+    qc = Fp8Config(is_checkpoint_fp8_serialized=False, activation_scheme="dynamic") if fp8 else None
+    blk = cls(HID, HEADS, 4.0, dtype=torch.bfloat16, prefix=prefix, quant_config=qc)
+    init_synthetic_weights(blk, seed=3, host_rng=True)
+    state = {f"{prefix}.{k}": v.detach().clone() for k, v in blk.state_dict().items()}
+    blk = blk.to(device)
+    process_weights_after_loading(blk)
+    return blk, state
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_double_stream_block_vs_oracle(device, fp8):
+    blk, state = _build(MMDoubleStreamBlock, device, fp8, "double_blocks.0")
+    orc = HunyuanBlocksOracle(state, num_heads=HEADS, fp8=fp8)
+    img, txt, vec, cos, sin = _inputs(2, 96, 24)
+    ri, rt = orc.double_block("double_blocks.0", img, txt, vec, cos, sin)
+    with torch.no_grad():
+        oi, ot = blk(img.to(device), txt.to(device), vec.to(device), (cos.to(device), sin.to(device)))
+    ei, et = rel_l2(oi, ri), rel_l2(ot, rt)
+    print(f"double block fp8={fp8}: img {ei:.2e} txt {et:.2e}")
+    # one attention call per block: the per-operator budget (2e-3 attention, 1e-3 elsewhere).
+    # W8A8: five quantised linears in a chain (qkv, proj, fc_in, fc_out); a one-ulp bf16
+    # difference upstream moves an e4m3 rounding (3 mantissa bits) downstream, as on the Flux path
+    tol = 2e-2 if fp8 else 4e-3
+    assert ei <= tol and et <= tol
+    if fp8:
+        assert blk.img_mlp.fc_in.weight.dtype == torch.float8_e4m3fn
+        assert blk.img_mod.linear.weight.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_single_stream_block_vs_oracle(device, fp8):
+    blk, state = _build(MMSingleStreamBlock, device, fp8, "single_blocks.0")
+    orc = HunyuanBlocksOracle(state, num_heads=HEADS, fp8=fp8)
+    img, txt, vec, cos, sin = _inputs(2, 80, 16, seed=1)
+    x = torch.cat([img, txt], dim=1)
+    ref = orc.single_block("single_blocks.0", x, vec, 16, cos, sin)
+    with torch.no_grad():
+        out = blk(x.to(device), vec.to(device), 16, (cos.to(device), sin.to(device)))
+    e = rel_l2(out, ref)
+    print(f"single block fp8={fp8}: {e:.2e}")
+    assert e <= (2e-2 if fp8 else 4e-3)
+
+
+def test_text_rows_are_not_rotated(device):
+    """The joint rotation table's identity rows leave the text q / k bit for bit at their
+    RMSNorm values: rotating the video angles must not change the text output's dependence
+    on its own q, and a zero-length video part is plain attention over the text."""
+    blk, state = _build(MMSingleStreamBlock, device, False, "single_blocks.0")
+    orc = HunyuanBlocksOracle(state, num_heads=HEADS)
+    _, txt, vec, _, _ = _inputs(1, 8, 32, seed=2)
+    empty = torch.zeros(0, HID // HEADS // 2)
+    ref = orc.single_block("single_blocks.0", txt, vec, 32, empty, empty)
+    with torch.no_grad():
+        out = blk(txt.to(device), vec.to(device), 32, (empty.to(device), empty.to(device)))
+    assert rel_l2(out, ref) <= 4e-3
