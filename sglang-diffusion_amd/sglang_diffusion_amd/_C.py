@@ -122,8 +122,12 @@ SIGNATURES = {
 _lib = None
 
 
+# the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
+ABI_VERSION = 3
+
+
 def load_library() -> ctypes.CDLL:
-    """dlopen the kernel library and attach prototypes; raises if it is missing."""
+    """dlopen the kernel library and attach prototypes; raises if it is missing or stale."""
     global _lib
     if _lib is not None:
         return _lib
@@ -137,6 +141,9 @@ def load_library() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.mi355_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI {lib.mi355_abi_version()}, this binding expects "
+                           f"{ABI_VERSION}: rebuild with `make -C sglang-diffusion_amd/csrc`")
     _lib = lib
     return lib
 

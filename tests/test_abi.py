@@ -34,7 +34,7 @@ def test_binding_table_matches_header():
 
 def test_error_reporting_without_gpu():
     lib = _C.load_library()
-    assert lib.mi355_abi_version() == 3
+    assert lib.mi355_abi_version() == _C.ABI_VERSION == 3
     # argument validation happens before any HIP call: a null pointer is rejected on the host
     rc = lib.mi355_per_token_quant_fp8(None, 4, 128, 128, None, None, None)
     assert rc == -1
@@ -54,3 +54,11 @@ def test_ops_refuse_cpu_tensors():
     s = torch.zeros(4)
     with pytest.raises(RuntimeError, match="HIP device"):
         _C.per_token_quant_fp8(x, q, s)
+
+
+def test_graft_entry_build_loads_the_library():
+    """build() is the driver's "does it build" check: it must run to the end here (make is a
+    no-op when the library is current)."""
+    import __graft_entry__ as g
+
+    g.build()
