@@ -271,7 +271,7 @@ def main():
             dist.destroy_process_group()
         return
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the host baseline belongs to the N = 1 line only
         try:
             cpu = cpu_baseline()
         except Exception as e:  # the baseline is informational; never lose the GPU line
