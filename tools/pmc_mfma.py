@@ -12,9 +12,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
-from pmc_traffic import short
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_traffic import short  # noqa: E402
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
