@@ -236,42 +236,101 @@ class LocalAttention(nn.Module):
 
 
 class USPAttention(nn.Module):
-    """layer.py:288-412.  With no sequence-parallel group (the data-parallel Flux path) this
-    is local attention; with a Ulysses group it does the head-scatter / sequence-gather
-    all-to-all around the local kernel (layers/usp.py:49-158)."""
+    """layer.py:288-470.  With no sequence-parallel group (the data-parallel Flux path) this
+    is local attention.  With a Ulysses group it does the head-scatter / sequence-gather
+    all-to-all around the local kernel (layers/usp.py:49-158); a leading run of tokens that is
+    REPLICATED on every rank (the text tokens of Flux's joint attention) stays out of the
+    exchange and is head-sliced locally instead (layer.py:414-470).  With a ring group the
+    exchanged tensors are attended ring-wise (layers/usp.py:161-252).
+
+    `attn_impl` may be given for tests without a GPU; the default is the HIP backend."""
 
     def __init__(self, num_heads: int, head_size: int, num_kv_heads: int | None = None,
                  softmax_scale: float | None = None, causal: bool = False,
                  supported_attention_backends=None, prefix: str = "", dropout_rate: float = 0.0,
-                 skip_sequence_parallel: bool = False, ulysses_group=None, **extra_impl_args):
+                 skip_sequence_parallel: bool = False, ulysses_group=None, ring_group=None,
+                 attn_impl=None, **extra_impl_args):
         super().__init__()
         self.softmax_scale = head_size ** -0.5 if softmax_scale is None else softmax_scale
         num_kv_heads = num_kv_heads or num_heads
-        backend = get_attn_backend(head_size, torch.bfloat16, supported_attention_backends)
-        self.attn_impl = backend.get_impl_cls()(num_heads=num_heads, head_size=head_size,
+        if attn_impl is None:
+            backend = get_attn_backend(head_size, torch.bfloat16, supported_attention_backends)
+            attn_impl = backend.get_impl_cls()(num_heads=num_heads, head_size=head_size,
                                                causal=causal, softmax_scale=self.softmax_scale,
                                                num_kv_heads=num_kv_heads, prefix=f"{prefix}.impl",
                                                **extra_impl_args)
+            self.backend = backend.get_enum()
+        self.attn_impl = attn_impl
         self.num_heads, self.head_size, self.num_kv_heads = num_heads, head_size, num_kv_heads
-        self.backend = backend.get_enum()
         self.causal = causal
         self.skip_sequence_parallel = skip_sequence_parallel
         self.ulysses_group = ulysses_group
+        self.ring_group = ring_group
+
+    @staticmethod
+    def _size(group) -> int:
+        import torch.distributed as dist
+
+        return dist.get_world_size(group) if (group is not None and dist.is_initialized()) else 1
 
     def forward(self, q, k, v, num_replicated_prefix: int = 0):
         md = get_forward_context().attn_metadata
-        group = self.ulysses_group
-        if self.skip_sequence_parallel or group is None or group.size() == 1:
+        up, rp = self._size(self.ulysses_group), self._size(self.ring_group)
+        if self.skip_sequence_parallel or (up == 1 and rp == 1):
             return self.attn_impl.forward(q, k, v, md)
-        if num_replicated_prefix:
-            raise NotImplementedError("replicated-prefix Ulysses (Flux-2) is not built")
+        if up > 1 and num_replicated_prefix > 0:
+            if rp > 1:
+                raise NotImplementedError("a replicated prefix under ring attention is not built")
+            return self._forward_with_replicated_prefix(q, k, v, md, num_replicated_prefix)
+        from ..runtime.parallel import ring_attention, ulysses_all_to_all
+
+        if up > 1:
+            qkv = ulysses_all_to_all(torch.cat([q, k, v], dim=0), self.ulysses_group,
+                                     scatter_dim=2, gather_dim=1)
+            q, k, v = qkv.chunk(3, dim=0)
+        if rp > 1:
+            if self.causal:
+                raise NotImplementedError("ring attention: causal masking is not built")
+            impl = self.attn_impl
+
+            def attn_fn(q_, k_, v_, scale):
+                return impl.forward(q_, k_, v_, md, return_softmax_lse=True)
+
+            merge = getattr(impl, "merge_states", None)
+            out, _ = ring_attention(q, k, v, self.ring_group, self.softmax_scale, attn_fn=attn_fn,
+                                    merge_fn=merge)
+        else:
+            out = self.attn_impl.forward(q, k, v, md)
+        if up > 1:
+            out = ulysses_all_to_all(out.contiguous(), self.ulysses_group, scatter_dim=1, gather_dim=2)
+        return out
+
+    def _forward_with_replicated_prefix(self, q, k, v, md, num_rep: int):
+        """layer.py:414-470: only the sharded suffix goes through the all-to-all (q, k, v stacked
+        in one exchange); the replicated prefix is sliced to this rank's heads, attention runs
+        on [prefix | gathered suffix], the suffix of the result is exchanged back and the
+        prefix's heads are all-gathered."""
+        import torch.distributed as dist
+
         from ..runtime.parallel import ulysses_all_to_all
 
-        q = ulysses_all_to_all(q, group, scatter_dim=2, gather_dim=1)
-        k = ulysses_all_to_all(k, group, scatter_dim=2, gather_dim=1)
-        v = ulysses_all_to_all(v, group, scatter_dim=2, gather_dim=1)
-        out = self.attn_impl.forward(q, k, v, md)
-        return ulysses_all_to_all(out, group, scatter_dim=1, gather_dim=2)
+        group = self.ulysses_group
+        P, rank = dist.get_world_size(group), dist.get_rank(group)
+        H = q.shape[2]
+        if H % P:
+            raise ValueError(f"{H} heads do not divide over {P} ranks")
+        shard = ulysses_all_to_all(torch.cat([q[:, num_rep:], k[:, num_rep:], v[:, num_rep:]], dim=0),
+                                   group, scatter_dim=2, gather_dim=1)
+        qs, ks, vs = shard.chunk(3, dim=0)
+        hs = slice(rank * (H // P), (rank + 1) * (H // P))
+        out = self.attn_impl.forward(torch.cat([q[:, :num_rep, hs], qs], dim=1),
+                                     torch.cat([k[:, :num_rep, hs], ks], dim=1),
+                                     torch.cat([v[:, :num_rep, hs], vs], dim=1), md)
+        out_shard = ulysses_all_to_all(out[:, num_rep:].contiguous(), group, scatter_dim=1,
+                                       gather_dim=2)
+        parts = [torch.empty_like(out[:, :num_rep]) for _ in range(P)]
+        dist.all_gather(parts, out[:, :num_rep].contiguous(), group=group)
+        return torch.cat([torch.cat(parts, dim=2), out_shard], dim=1)
 
 
 class UlyssesAttention(nn.Module):

@@ -166,10 +166,20 @@ def test_ring_attention_two_ranks_equals_dense():
 class _OracleImpl:
     """Attention implementation stand-in for the CPU: the oracle's dense attention."""
 
-    def forward(self, q, k, v, attn_metadata=None):
+    def forward(self, q, k, v, attn_metadata=None, return_softmax_lse=False):
         from oracle import ops as O
 
-        return O.attention(q, k, v)
+        return O.attention(q, k, v, return_lse=return_softmax_lse)
+
+    @staticmethod
+    def merge_states(out, lse, a, a_lse, b, b_lse):
+        from oracle import ops as O
+
+        B, S, H, D = a.shape
+        vm, sm = O.merge_attn_states(a.reshape(B * S, H, D), a_lse.transpose(1, 2).reshape(B * S, H),
+                                     b.reshape(B * S, H, D), b_lse.transpose(1, 2).reshape(B * S, H))
+        out.copy_(vm.view(B, S, H, D))
+        lse.copy_(sm.view(B, S, H).transpose(1, 2))
 
 
 def _ulysses_replicated_case(rank):
@@ -198,3 +208,37 @@ def test_ulysses_attention_with_replicated_text():
     ret = _run(_ulysses_replicated_case)
     for rank in range(WORLD):
         assert ret[rank] == (True, True), ret[rank]
+
+
+def _usp_case(rank):
+    """USPAttention on two ranks: (a) Flux joint attention with the text prefix replicated
+    (layer.py:414-470) equals dense attention over [text | image] bit for bit; (b) the ring
+    variant over a sequence sharded in q AND k/v equals dense attention within the extra
+    rounding of the partial results."""
+    from oracle import ops as O
+    from sglang_diffusion_amd.layers.attention import USPAttention
+    from sglang_diffusion_amd.layers.forward_context import set_forward_context
+
+    B, T, S, H, D = 1, 5, 16, 4, 16
+    g = torch.Generator().manual_seed(21)
+    txt = torch.randn(3, B, T, H, D, generator=g).bfloat16()
+    img = torch.randn(3, B, S, H, D, generator=g).bfloat16()
+    sl = slice(rank * S // WORLD, (rank + 1) * S // WORLD)
+    local = [torch.cat([txt[i], img[i][:, sl]], dim=1) for i in range(3)]
+    ref = O.attention(*[torch.cat([txt[i], img[i]], dim=1) for i in range(3)])
+    want = torch.cat([ref[:, :T], ref[:, T:][:, sl]], dim=1)
+    with set_forward_context(current_timestep=0, attn_metadata=None):
+        layer = USPAttention(H, D, ulysses_group=dist.group.WORLD, attn_impl=_OracleImpl())
+        out = layer(local[0], local[1], local[2], num_replicated_prefix=T)
+        ring = USPAttention(H, D, ring_group=dist.group.WORLD, attn_impl=_OracleImpl())
+        r_out = ring(img[0][:, sl].contiguous(), img[1][:, sl].contiguous(), img[2][:, sl].contiguous())
+    r_ref = O.attention(img[0][:, sl], img[1], img[2])
+    r_err = float((r_out.float() - r_ref.float()).norm() / r_ref.float().norm())
+    return torch.equal(out, want), r_err
+
+
+def test_usp_attention_replicated_prefix_and_ring():
+    ret = _run(_usp_case)
+    for rank in range(WORLD):
+        ok, r_err = ret[rank]
+        assert ok and r_err <= 6e-3, ret[rank]
