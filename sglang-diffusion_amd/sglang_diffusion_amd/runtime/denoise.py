@@ -48,8 +48,13 @@ class Req:
 
 class DenoisingStage:
     def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None,
-                 fused: bool = True, cfg_batched: bool = True):
+                 fused: bool = True, cfg_batched: bool = True, cfg_group=None):
+        """cfg_group: a 2-rank process group over which the conditional (rank 0) and the
+        unconditional (rank 1) branch of true CFG are split (the reference's
+        enable_cfg_parallel, pipelines_core/stages/denoising.py:1388-1446); None = both
+        branches on this rank."""
         self.transformer = transformer
+        self.cfg_group = cfg_group
         # Flux ships use_dynamic_shifting=True in its scheduler config
         self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=True)
         self.fused = fused
@@ -92,6 +97,18 @@ class DenoisingStage:
                                  encoder_hidden_states=batch.prompt_embeds,
                                  pooled_projections=batch.pooled_embeds, timestep=timestep,
                                  guidance=guidance, freqs_cis=freqs).clone()
+            if self.cfg_group is not None:
+                import torch.distributed as dist
+
+                from .parallel import cfg_parallel_combine
+
+                neg = dist.get_rank(self.cfg_group) != 0
+                mine = self._dit(
+                    hidden_states=latent_model_input,
+                    encoder_hidden_states=batch.negative_prompt_embeds if neg else batch.prompt_embeds,
+                    pooled_projections=batch.neg_pooled_embeds if neg else batch.pooled_embeds,
+                    timestep=timestep, guidance=guidance, freqs_cis=freqs).clone()
+                return cfg_parallel_combine(mine, float(batch.guidance_scale), self.cfg_group)
             if self.cfg_batched:
                 # cond and uncond of every request ride in ONE forward of batch 2B: rows of a
                 # batch never interact inside the DiT, so this equals two separate passes.

@@ -10,7 +10,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from sglang_diffusion_amd.runtime.batch_scheduler import DataParallelBatchScheduler, merge_requests
-from sglang_diffusion_amd.runtime.parallel import (gather_latents, init_distributed, ring_attention,
+from sglang_diffusion_amd.runtime.parallel import (cfg_parallel_combine, gather_latents,
+                                                   init_distributed, ring_attention,
                                                    shard_requests,
                                                    ulysses_all_to_all)
 from sglang_diffusion_amd.runtime.synthetic import make_synthetic_request
@@ -242,3 +243,21 @@ def test_usp_attention_replicated_prefix_and_ring():
     for rank in range(WORLD):
         ok, r_err = ret[rank]
         assert ok and r_err <= 6e-3, ret[rank]
+
+
+def _cfg_parallel_case(rank):
+    """The two guidance branches on two ranks (denoising.py:1436-1446): the all-reduced sum is
+    s * cond + (1 - s) * uncond with eager bf16 rounding of each product and of the sum."""
+    g = torch.Generator().manual_seed(5)
+    cond = torch.randn(2, 16, 8, generator=g).bfloat16()
+    uncond = torch.randn(2, 16, 8, generator=g).bfloat16()
+    s = 3.5
+    out = cfg_parallel_combine(cond if rank == 0 else uncond, s, dist.group.WORLD,
+                               scale_fn=lambda x, a: a * x)
+    want = s * cond + (1 - s) * uncond
+    return torch.equal(out, want)
+
+
+def test_cfg_parallel_combine_two_ranks():
+    ret = _run(_cfg_parallel_case)
+    assert ret[0] and ret[1]

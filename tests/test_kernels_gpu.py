@@ -451,6 +451,16 @@ def test_attention_over_key_halves_merges_to_the_whole(device):
     assert (la - lse_w).abs().max().item() <= 2e-5
 
 
+def test_cfg_parallel_partial_product_is_the_eager_bf16_product(device):
+    """The per-rank contribution of CFG parallelism, s * pred in bf16 (denoising.py:1438-1444),
+    through the guidance-combine kernel with a zero second operand."""
+    from sglang_diffusion_amd.runtime.parallel import _hip_scale
+
+    x = (torch.randn(3, 4096, 64, generator=g(95)) * 2).bfloat16().to(device)
+    for s in (3.5, 1.0 - 3.5, 0.0, 1.0):
+        assert torch.equal(_hip_scale(x, s), s * x)
+
+
 # ------------------------------------------------------------------------- norm / rope --
 @pytest.mark.parametrize("rows,dim,wf32", [(37, 128, True), (5, 3072, False), (1000, 128, True)])
 def test_rmsnorm_vs_oracle(device, rows, dim, wf32):
