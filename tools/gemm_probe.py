@@ -34,7 +34,6 @@ def bench(fp8, M, N, K, iters=20, block=False, **kw):
     print(f"{'fp8-block' if block else 'fp8' if fp8 else 'bf16'} M={M} N={N} K={K}: {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF/s", flush=True)
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "both"
-print("MI355_GEMM_DBG =", os.environ.get("MI355_GEMM_DBG"))
 if mode in ("fp8", "both"):
     for (M, N, K) in [(16384, 9216, 3072), (18432, 12288, 3072), (18432, 3072, 15360), (8192, 8192, 8192)]:
         bench(True, M, N, K)
