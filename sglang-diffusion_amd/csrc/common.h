@@ -56,8 +56,6 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
   return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
 }
 
-// ---- f32 -> fp8 e4m3fn (OCP on gfx950), round-to-nearest-even ---------------
-// v_cvt_pk_fp8_f32 converts two floats into two bytes of a dword.
 // two floats -> bf16 (round to nearest even, the linear's result) -> the same values in IEEE
 // half, packed lo | hi << 16.  Exact for bf16 values inside half's normal range.
 __device__ __forceinline__ unsigned int pack_bf2_as_f16(float lo, float hi) {
@@ -68,6 +66,8 @@ __device__ __forceinline__ unsigned int pack_bf2_as_f16(float lo, float hi) {
   return __builtin_bit_cast(unsigned int, v);
 }
 
+// ---- f32 -> fp8 e4m3fn (OCP on gfx950), round-to-nearest-even ---------------
+// v_cvt_pk_fp8_f32 converts two floats into two bytes of a dword.
 __device__ __forceinline__ unsigned int cvt4_fp8(float a, float b, float c, float d) {
   int w = 0;
   w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
