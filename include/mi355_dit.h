@@ -37,7 +37,8 @@ const char* mi355_last_error(void);
 /* 2: mi355_linear_args gained f16_begin/f16_end; mi355_flash_attn_fwd_f16v and
  *    mi355_bf16_to_f16 were added.
  * 3: mi355_linear_args gained block_scale and the four scale strides;
- *    mi355_layernorm_modulate_group_quant and mi355_merge_attn_states were added. */
+ *    mi355_layernorm_modulate_group_quant and mi355_merge_attn_states were added.
+ * 4: mi355_flash_attn_fwd_ex was added; mi355_qk_norm_rope accepts q == NULL. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -217,7 +218,8 @@ int mi355_fused_add_rmsnorm(void* x, void* residual, const void* w, int w_is_f32
  * Tokens s < s_split use weights (wq0,wk0) (the text stream's
  * norm_added_q/k), the rest (wq1,wk1); pass the same pointers for a single
  * stream.  Weights fp32 [D] or NULL to skip the norm.  cos,sin fp32 [S, D/2]
- * or NULL to skip the rotation; position of token s is s. */
+ * or NULL to skip the rotation; position of token s is s.  q may be NULL: only k is processed
+ * then (mi355_flash_attn_fwd_ex can do the query side while it loads Q). */
 int mi355_qk_norm_rope(void* q, void* k, int64_t B, int64_t S, int64_t H, int64_t D,
                        int64_t sb, int64_t ss, int64_t sh, const float* wq0,
                        const float* wk0, const float* wq1, const float* wk1,
@@ -292,6 +294,34 @@ int mi355_euler_step(void* out, const void* sample, const void* v, float sigma,
  *   out = bf16(u + bf16(s * bf16(c - u))). */
 int mi355_cfg_combine(void* out, const void* cond, const void* uncond, float scale,
                       int64_t n, void* stream);
+
+/* Every option of the attention kernel in one argument block; the two entry points above are
+ * this call with v_is_f16 = 0 / 1 and no query transform.
+ * Query transform (optional): per-head RMSNorm and interleaved RoPE applied to each Q row as the
+ * kernel loads it, with exactly the arithmetic (and summation order) of mi355_qk_norm_rope on
+ * q -- rows s < q_split use q_norm_w0, the rest q_norm_w1 (fp32 [D], both or neither);
+ * q_cos / q_sin fp32 [Sq, D/2] (both or neither); position of row s is s.  The q tensor in
+ * memory is left untouched.  Saves the read-modify-write pass over Q
+ * (apply_qk_norm + apply_flashinfer_rope_qk_inplace, models/dits/flux.py:356-395). */
+typedef struct {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* out;
+  float* lse; /* fp32 [B,H,Sq] or NULL */
+  int64_t B, Sq, Sk, H, Hk, D;
+  int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
+  float softmax_scale;
+  int causal;
+  int v_is_f16;
+  const float* q_norm_w0;
+  const float* q_norm_w1;
+  int64_t q_split;
+  float q_eps;
+  const float* q_cos;
+  const float* q_sin;
+} mi355_attn_args;
+int mi355_flash_attn_fwd_ex(const mi355_attn_args* args, void* stream);
 
 /* Merge of two partial attention results over disjoint key sets (ring / context-parallel
  * attention): out = (a e^(la-m) + b e^(lb-m)) / (e^(la-m) + e^(lb-m)), lse = log(sum) + m,

@@ -43,6 +43,13 @@ struct AttnParams {
   int B, Sq, Sk, H, Hk;
   int64_t q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;
   float scale_log2;  // softmax_scale * log2(e)
+  // optional transform of Q while it is loaded: per-head RMSNorm, interleaved RoPE
+  const float* qw0;
+  const float* qw1;
+  int q_split;
+  float q_eps;
+  const float* qcos;
+  const float* qsin;
 };
 
 __device__ __forceinline__ int k_swz(int key) { return key & 15; }
@@ -88,6 +95,60 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s)
       qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * hh);
+    if (p.qw1 || p.qcos) {
+      // Same arithmetic and summation order as qk_norm_rope_kernel (elementwise.hip), where 16
+      // (or 8) lanes hold one row in 8-element chunks: here chunk 2s + hh of the row sits in
+      // step s of this lane and chunk 2s + (1 - hh) in the lane 32 away, so the butterfly over
+      // chunk-index bits 3, 2, 1 runs inside the lane and bit 0 is one exchange.
+      float f[KSTEPS][8];
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[s][j] = (float)qf[s][j];
+      const float* wsel = qrow < p.q_split ? p.qw0 : p.qw1;
+      if (wsel) {
+        float c[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          c[s] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) c[s] += f[s][j] * f[s][j];
+        }
+#pragma unroll
+        for (int w = KSTEPS / 2; w >= 1; w >>= 1)
+#pragma unroll
+          for (int s = 0; s < w; ++s) c[s] = c[s] + c[s + w];
+        const float sq = c[0] + __shfl_xor(c[0], 32, 64);
+        const float rs = rsqrtf(sq / (float)D + p.q_eps);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          const f32x4 wa = reinterpret_cast<const f32x4*>(wsel)[2 * (2 * s + hh)];
+          const f32x4 wb = reinterpret_cast<const f32x4*>(wsel)[2 * (2 * s + hh) + 1];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f[s][j] = rbf((f[s][j] * rs) * wa[j]);
+            f[s][4 + j] = rbf((f[s][4 + j] * rs) * wb[j]);
+          }
+        }
+      }
+      if (p.qcos) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          const f32x4 cs = reinterpret_cast<const f32x4*>(p.qcos + (int64_t)qrow * (D / 2))[2 * s + hh];
+          const f32x4 sn = reinterpret_cast<const f32x4*>(p.qsin + (int64_t)qrow * (D / 2))[2 * s + hh];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x1 = f[s][2 * j], x2 = f[s][2 * j + 1];
+            f[s][2 * j] = fmaf(-x2, sn[j], __fmul_rn(x1, cs[j]));
+            f[s][2 * j + 1] = fmaf(x1, sn[j], __fmul_rn(x2, cs[j]));
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)f[s][j];
+    }
   }
 
   // ---- LDS-DMA sources: piece = 1 KiB = 1024/ROWB rows; [K tile | V tile] ----
@@ -391,7 +452,9 @@ static int attn_entry(const void* q, const void* k, const void* v, void* out, fl
                       int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss,
                       int64_t k_sh, int64_t v_sb, int64_t v_ss, int64_t v_sh, int64_t o_sb,
                       int64_t o_ss, int64_t o_sh, float softmax_scale, int causal, bool v_f16,
-                      void* stream) {
+                      void* stream, const float* qw0 = nullptr, const float* qw1 = nullptr,
+                      int64_t q_split = 0, float q_eps = 0.f, const float* qcos = nullptr,
+                      const float* qsin = nullptr) {
   MI355_REQUIRE(q && k && v && out, "flash_attn_fwd: null pointer");
   if (causal) {
     mi355_set_error("flash_attn_fwd: causal masking is not built (the DiT path is non-causal)");
@@ -410,6 +473,11 @@ static int attn_entry(const void* q, const void* k, const void* v, void* out, fl
   MI355_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
                     ((uintptr_t)out % 16) == 0,
                 "flash_attn_fwd: q/k/v/out must be 16-byte aligned");
+  MI355_REQUIRE((qw0 == nullptr) == (qw1 == nullptr) && (qcos == nullptr) == (qsin == nullptr),
+                "flash_attn_fwd: the query norm weights, and cos / sin, come in pairs");
+  MI355_REQUIRE(((uintptr_t)qw0 % 16) == 0 && ((uintptr_t)qw1 % 16) == 0 &&
+                    ((uintptr_t)qcos % 16) == 0 && ((uintptr_t)qsin % 16) == 0,
+                "flash_attn_fwd: query transform tables must be 16-byte aligned");
   if (B == 0 || Sq == 0) return MI355_OK;
   MI355_REQUIRE(Sk > 0, "flash_attn_fwd: empty key sequence");
   AttnParams p;
@@ -428,6 +496,12 @@ static int attn_entry(const void* q, const void* k, const void* v, void* out, fl
   p.v_sb = v_sb; p.v_ss = v_ss; p.v_sh = v_sh;
   p.o_sb = o_sb; p.o_ss = o_ss; p.o_sh = o_sh;
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
+  p.qw0 = qw0;
+  p.qw1 = qw1;
+  p.q_split = (int)(q_split < 0 ? 0 : (q_split > Sq ? Sq : q_split));
+  p.q_eps = q_eps;
+  p.qcos = qcos;
+  p.qsin = qsin;
   hipStream_t st = (hipStream_t)stream;
   if (v_f16) return D == 128 ? launch_attn<128, true, true>(p, st) : launch_attn<64, true, true>(p, st);
   static const bool no_tr = getenv("MI355_ATTN_NO_TR") != nullptr;  // debugging aid
@@ -456,4 +530,12 @@ extern "C" int mi355_flash_attn_fwd_f16v(const void* q, const void* k, const voi
                                          int causal, void* stream) {
   return attn_entry(q, k, v, out, lse, B, Sq, Sk, H, Hk, D, q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb,
                     v_ss, v_sh, o_sb, o_ss, o_sh, softmax_scale, causal, true, stream);
+}
+
+extern "C" int mi355_flash_attn_fwd_ex(const mi355_attn_args* a, void* stream) {
+  MI355_REQUIRE(a != nullptr, "flash_attn_fwd_ex: null args");
+  return attn_entry(a->q, a->k, a->v, a->out, a->lse, a->B, a->Sq, a->Sk, a->H, a->Hk, a->D, a->q_sb,
+                    a->q_ss, a->q_sh, a->k_sb, a->k_ss, a->k_sh, a->v_sb, a->v_ss, a->v_sh, a->o_sb,
+                    a->o_ss, a->o_sh, a->softmax_scale, a->causal, a->v_is_f16 != 0, stream,
+                    a->q_norm_w0, a->q_norm_w1, a->q_split, a->q_eps, a->q_cos, a->q_sin);
 }

@@ -136,10 +136,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
   const int sub = threadIdx.x % LPR;
   const int64_t rows_one = B * S * H;
   const int64_t gr = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
-  const bool live = gr < 2 * rows_one;
-  const int64_t g = live ? gr : 2 * rows_one - 1;
-  const bool is_k = g >= rows_one;
-  const int64_t rrow = is_k ? g - rows_one : g;
+  // q == nullptr: only the key rows are processed (the query side is done by the attention
+  // kernel as it loads Q)
+  const int64_t rows_all = q ? 2 * rows_one : rows_one;
+  const bool live = gr < rows_all;
+  const int64_t g = live ? gr : rows_all - 1;
+  const bool is_k = q ? g >= rows_one : true;
+  const int64_t rrow = (q && is_k) ? g - rows_one : g;
   const int64_t hh = rrow % H;
   const int64_t tok = rrow / H;
   const int64_t s = tok % S;
@@ -535,7 +538,7 @@ extern "C" int mi355_qk_norm_rope(void* q, void* k, int64_t B, int64_t S, int64_
                                   const float* wk0, const float* wq1, const float* wk1,
                                   int64_t s_split, float eps, const float* cos, const float* sin,
                                   int interleaved, void* stream) {
-  MI355_REQUIRE(q && k, "qk_norm_rope: null pointer");
+  MI355_REQUIRE(k, "qk_norm_rope: null key pointer");
   MI355_REQUIRE(D == 128 || D == 64, "qk_norm_rope: head size %ld not in {64,128}", (long)D);
   MI355_REQUIRE(B >= 0 && S >= 0 && H > 0, "qk_norm_rope: bad shape");
   MI355_REQUIRE(sb % 8 == 0 && ss % 8 == 0 && sh % 8 == 0 && ((uintptr_t)q % 16) == 0 &&
@@ -548,7 +551,7 @@ extern "C" int mi355_qk_norm_rope(void* q, void* k, int64_t B, int64_t S, int64_
   if (cos)
     MI355_REQUIRE(((uintptr_t)cos % 16) == 0 && ((uintptr_t)sin % 16) == 0,
                   "qk_norm_rope: cos/sin must be 16-byte aligned");
-  const int64_t rows = 2 * B * S * H;
+  const int64_t rows = (q ? 2 : 1) * B * S * H;
   if (rows == 0) return MI355_OK;
   hipStream_t st = (hipStream_t)stream;
   if (D == 128) {

@@ -60,6 +60,17 @@ class LinearArgs(ctypes.Structure):
     ]
 
 
+class AttnArgs(ctypes.Structure):
+    _fields_ = (
+        [(n, _ptr) for n in ("q", "k", "v", "out", "lse")]
+        + [(n, _i64) for n in ("B", "Sq", "Sk", "H", "Hk", "D", "q_sb", "q_ss", "q_sh", "k_sb", "k_ss",
+                               "k_sh", "v_sb", "v_ss", "v_sh", "o_sb", "o_ss", "o_sh")]
+        + [("softmax_scale", _f32), ("causal", _int), ("v_is_f16", _int),
+           ("q_norm_w0", _ptr), ("q_norm_w1", _ptr), ("q_split", _i64), ("q_eps", _f32),
+           ("q_cos", _ptr), ("q_sin", _ptr)]
+    )
+
+
 # every symbol include/mi355_dit.h declares, with its argument types
 SIGNATURES = {
     "mi355_last_error": (ctypes.c_char_p, []),
@@ -105,6 +116,7 @@ SIGNATURES = {
         _int,
         [_ptr] * 5 + [_i64] * 5 + [_f32, ctypes.POINTER(RowMap), _ptr],
     ),
+    "mi355_flash_attn_fwd_ex": (_int, [ctypes.POINTER(AttnArgs), _ptr]),
     "mi355_merge_attn_states": (
         _int,
         [_ptr] * 6 + [_i64] * 4 + [ctypes.POINTER(_i64)] * 6 + [_ptr],
@@ -123,7 +135,7 @@ _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def load_library() -> ctypes.CDLL:
@@ -269,28 +281,38 @@ def linear_ex(
 
 # ----------------------------------------------------------------- attention --
 def flash_attn_fwd(q, k, v, out, lse, softmax_scale: float, causal: bool = False,
-                   v_is_f16: bool = False) -> None:
+                   v_is_f16: bool = False, q_norm=None, q_rope=None) -> None:
     """q [B,Sq,H,D], k/v [B,Sk,Hk,D], out [B,Sq,H,D] (last dim contiguous).  With v_is_f16 the
-    16-bit words of `v` hold IEEE half values and P.V runs in half (more accurate)."""
+    16-bit words of `v` hold IEEE half values and P.V runs in half (more accurate).
+    q_norm = (w0, w1, split, eps) and q_rope = (cos, sin) make the kernel apply the per-head
+    RMSNorm and the interleaved RoPE of qk_norm_rope to each Q row as it loads it (q itself is
+    not modified)."""
     B, Sq, H, D = q.shape
     Sk, Hk = k.shape[1], k.shape[2]
     for t in (q, k, v, out):
         if t.stride(-1) != 1:
             raise RuntimeError("flash_attn_fwd: last dimension must be contiguous")
-    lib = load_library()
-    fn = lib.mi355_flash_attn_fwd_f16v if v_is_f16 else lib.mi355_flash_attn_fwd
-    _check(
-        fn(
-            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _p(lse),
-            B, Sq, Sk, H, Hk, D,
-            q.stride(0), q.stride(1), q.stride(2),
-            k.stride(0), k.stride(1), k.stride(2),
-            v.stride(0), v.stride(1), v.stride(2),
-            out.stride(0), out.stride(1), out.stride(2),
-            float(softmax_scale), int(bool(causal)), _stream(q),
-        ),
-        "flash_attn_fwd",
-    )
+    a = AttnArgs()
+    a.q, a.k, a.v, a.out, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), _p(lse)
+    a.B, a.Sq, a.Sk, a.H, a.Hk, a.D = B, Sq, Sk, H, Hk, D
+    a.q_sb, a.q_ss, a.q_sh = q.stride(0), q.stride(1), q.stride(2)
+    a.k_sb, a.k_ss, a.k_sh = k.stride(0), k.stride(1), k.stride(2)
+    a.v_sb, a.v_ss, a.v_sh = v.stride(0), v.stride(1), v.stride(2)
+    a.o_sb, a.o_ss, a.o_sh = out.stride(0), out.stride(1), out.stride(2)
+    a.softmax_scale, a.causal, a.v_is_f16 = float(softmax_scale), int(bool(causal)), int(bool(v_is_f16))
+    if q_norm is not None:
+        w0, w1, split, eps = q_norm
+        for w in (w0, w1):
+            if w.dtype != torch.float32 or w.numel() != D or not w.is_contiguous():
+                raise RuntimeError("flash_attn_fwd: query norm weights must be contiguous fp32 [D]")
+        a.q_norm_w0, a.q_norm_w1, a.q_split, a.q_eps = w0.data_ptr(), w1.data_ptr(), int(split), float(eps)
+    if q_rope is not None:
+        cos, sin = q_rope
+        for t in (cos, sin):
+            if t.dtype != torch.float32 or tuple(t.shape) != (Sq, D // 2) or not t.is_contiguous():
+                raise RuntimeError("flash_attn_fwd: query cos / sin must be contiguous fp32 [Sq, D/2]")
+        a.q_cos, a.q_sin = cos.data_ptr(), sin.data_ptr()
+    _check(load_library().mi355_flash_attn_fwd_ex(ctypes.byref(a), _stream(q)), "flash_attn_fwd")
 
 
 def merge_attn_states(out, out_lse, a, a_lse, b, b_lse, lse_layout: str = "bhs") -> None:
@@ -378,15 +400,18 @@ def fused_add_rmsnorm(x, residual, w, eps: float) -> None:
 
 
 def qk_norm_rope(q, k, wq0, wk0, wq1, wk1, s_split, eps, cos, sin, interleaved=True) -> None:
-    """In place on q, k [B,S,H,D] (strided views are fine, D contiguous)."""
-    B, S, H, D = q.shape
-    if q.stride() != k.stride() or q.stride(-1) != 1:
+    """In place on q, k [B,S,H,D] (strided views are fine, D contiguous); q may be None (the
+    query side is then left to flash_attn_fwd's q_norm / q_rope)."""
+    B, S, H, D = k.shape
+    if q is not None and (q.stride() != k.stride() or q.stride(-1) != 1):
         raise RuntimeError("qk_norm_rope: q and k must share strides, D contiguous")
+    if k.stride(-1) != 1:
+        raise RuntimeError("qk_norm_rope: D must be contiguous")
     _check(
         load_library().mi355_qk_norm_rope(
-            q.data_ptr(), k.data_ptr(), B, S, H, D, q.stride(0), q.stride(1), q.stride(2),
+            _p(q), k.data_ptr(), B, S, H, D, k.stride(0), k.stride(1), k.stride(2),
             _p(wq0), _p(wk0), _p(wq1), _p(wk1), int(s_split), float(eps), _p(cos), _p(sin),
-            int(bool(interleaved)), _stream(q),
+            int(bool(interleaved)), _stream(k),
         ),
         "qk_norm_rope",
     )

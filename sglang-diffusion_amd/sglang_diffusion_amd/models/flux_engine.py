@@ -11,7 +11,8 @@ the hardware:
     their stream's rows through a row map.
   * q, k, v come out of one fused projection GEMM per stream ([3D, D] weight, per-channel
     scales concatenated) straight into a joint [B, S, 3, H, d] buffer; RMSNorm + RoPE run
-    in place on its q/k slices; the attention kernel reads the strided views.
+    in place on its k slice, and on q inside the attention kernel as it loads its Q rows;
+    the attention kernel reads the strided views.
   * LayerNorm + AdaLN modulation + dynamic per-token fp8 quantisation is one pass over the
     hidden state; `gate * y + residual` is the epilogue of the GEMM that produces y.
   * All 19*2 + 38 + 1 AdaLN modulation linears are one weight-streaming GEMM per step.
@@ -284,10 +285,12 @@ class FluxEngine:
                                           (blk["add_qkv"], ot, Tt, map_t, Mt)):
                 a, sa = norm_in(pk.fp8, chunk(off, 0), chunk(off, 1), T, rmap, M)
                 self._lin(pk, a, qkv, M=M, sa=sa, o_map=rmap, f16_cols=vcols)
-            self._run("elementwise", 0.0, 8.0 * Ms * D, _C.qk_norm_rope, q, k, blk["naq"],
+            # RMSNorm + RoPE: in place on k; the attention kernel does q's as it loads Q
+            self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["naq"],
                       blk["nak"], blk["nq"], blk["nk"], Tt, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
-                      attn4, None, scale, False, True)
+                      attn4, None, scale, False, True,
+                      q_norm=(blk["naq"], blk["nq"], Tt, blk["eps"]), q_rope=(cos, sin))
             if blk["to_out"].fp8:
                 self._run("elementwise", 0.0, 3.0 * Ms * D, quant, attn, ws["aq"], ws["as_"])
                 a_src, a_s = ws["aq"], ws["as_"]
@@ -317,10 +320,11 @@ class FluxEngine:
             a, sa = norm_in(blk["qkv"].fp8, chunk(off, 0), chunk(off, 1), S, None, Ms)
             self._lin(blk["qkv"], a, qkv, M=Ms, sa=sa, f16_cols=vcols)
             self._lin(blk["mlp"], a, mlp_cols, M=Ms, sa=sa, act=1, ldo=catw)
-            self._run("elementwise", 0.0, 8.0 * Ms * D, _C.qk_norm_rope, q, k, blk["nq"], blk["nk"],
-                      blk["nq"], blk["nk"], 0, blk["eps"], cos, sin, True)
+            self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["nq"],
+                      blk["nk"], blk["nq"], blk["nk"], 0, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
-                      attn_in_cat, None, scale, False, True)
+                      attn_in_cat, None, scale, False, True,
+                      q_norm=(blk["nq"], blk["nq"], 0, blk["eps"]), q_rope=(cos, sin))
             if blk["out"].fp8:
                 self._run("elementwise", 0.0, 3.0 * Ms * catw, quant, cat, ws["cq"], ws["cs"])
                 c_src, c_s = ws["cq"], ws["cs"]

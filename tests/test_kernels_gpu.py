@@ -461,6 +461,48 @@ def test_cfg_parallel_partial_product_is_the_eager_bf16_product(device):
         assert torch.equal(_hip_scale(x, s), s * x)
 
 
+@pytest.mark.parametrize("B,S,H,D,split", [(2, 200, 3, 128, 37), (1, 130, 2, 64, 0), (1, 96, 2, 128, 96)])
+def test_attention_with_query_transform_equals_the_separate_pass(device, B, S, H, D, split):
+    """RMSNorm + interleaved RoPE applied to Q inside the attention kernel == the standalone
+    qk_norm_rope pass on q followed by plain attention, bit for bit; qk_norm_rope with q = None
+    touches only k."""
+    qkv = (torch.randn(B, S, 3, H, D, generator=g(101)) * 1.3).bfloat16().to(device)
+    w = [(torch.rand(D, generator=g(102 + i)) + 0.5).to(device) for i in range(4)]
+    ang = torch.rand(S, D // 2, generator=g(110)) * 6.28
+    cos, sin = torch.cos(ang).to(device), torch.sin(ang).to(device)
+    scale = D ** -0.5
+    # reference: both sides in place, then attention
+    ref = qkv.clone()
+    _C.qk_norm_rope(ref[:, :, 0], ref[:, :, 1], w[0], w[1], w[2], w[3], split, 1e-6, cos, sin, True)
+    v16 = _C.value_to_f16(ref[:, :, 2])
+    o_ref = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=device)
+    l_ref = torch.empty(B, H, S, dtype=torch.float32, device=device)
+    _C.flash_attn_fwd(ref[:, :, 0], ref[:, :, 1], v16, o_ref, l_ref, scale, False, True)
+    # fused: k only in place, q transformed on load
+    got = qkv.clone()
+    _C.qk_norm_rope(None, got[:, :, 1], w[0], w[1], w[2], w[3], split, 1e-6, cos, sin, True)
+    assert torch.equal(got[:, :, 1], ref[:, :, 1]) and torch.equal(got[:, :, 0], qkv[:, :, 0])
+    o = torch.empty_like(o_ref)
+    l = torch.empty_like(l_ref)
+    _C.flash_attn_fwd(got[:, :, 0], got[:, :, 1], v16, o, l, scale, False, True,
+                      q_norm=(w[0], w[2], split, 1e-6), q_rope=(cos, sin))
+    assert torch.equal(o, o_ref) and torch.equal(l, l_ref)
+    assert torch.equal(got[:, :, 0], qkv[:, :, 0]), "q in memory must stay untouched"
+    # each half alone
+    only_norm = qkv.clone()
+    _C.qk_norm_rope(only_norm[:, :, 0], only_norm[:, :, 1], w[0], w[1], w[2], w[3], split, 1e-6,
+                    None, None, True)
+    o1 = torch.empty_like(o_ref)
+    _C.flash_attn_fwd(only_norm[:, :, 0], got[:, :, 1], v16, o1, None, scale, False, True)
+    o2 = torch.empty_like(o_ref)
+    _C.flash_attn_fwd(qkv[:, :, 0], got[:, :, 1], v16, o2, None, scale, False, True,
+                      q_norm=(w[0], w[2], split, 1e-6))
+    assert torch.equal(o1, o2)
+    with pytest.raises(RuntimeError):
+        _C.flash_attn_fwd(qkv[:, :, 0], got[:, :, 1], v16, o2, None, scale, False, True,
+                          q_rope=(cos[:-1], sin[:-1]))
+
+
 # ------------------------------------------------------------------------- norm / rope --
 @pytest.mark.parametrize("rows,dim,wf32", [(37, 128, True), (5, 3072, False), (1000, 128, True)])
 def test_rmsnorm_vs_oracle(device, rows, dim, wf32):
