@@ -24,7 +24,7 @@ def bench(fp8, M, N, K, iters=20, block=False, **kw):
     bias = torch.randn(N, device=dev).bfloat16()
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     run = lambda: _C.linear_ex(a, w, out, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, sa=sa, sb=sb, bias=bias, fp8=fp8, **kw)
-    for _ in range(3): run()
+    for _ in range(10): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -41,6 +41,14 @@ if mode == "block":
     for (M, N, K) in [(16384, 9216, 3072), (18432, 12288, 3072), (18432, 3072, 15360), (8192, 8192, 8192),
                       (18432, 3072, 3072), (2048, 9216, 3072)]:
         bench(True, M, N, K, block=True)
+if mode == "tail":
+    # same N, K with and without a partial last round of 256x256 tiles over 256 CUs
+    for (M, N, K) in [(16384, 3072, 15360), (18432, 3072, 15360), (21504, 3072, 15360),
+                      (16384, 9216, 3072), (18432, 9216, 3072), (2048, 9216, 3072), (1792, 9216, 3072),
+                      (18432, 12288, 3072), (20480, 12288, 3072)]:
+        t = (M // 256) * (N // 256)
+        print(f"tiles {t} = {t / 256:.3f} rounds", flush=True)
+        bench(True, M, N, K)
 if mode in ("bf16", "both"):
     for (M, N, K) in [(16384, 12288, 3072), (16384, 3072, 12288), (8192, 8192, 8192)]:
         bench(False, M, N, K)
