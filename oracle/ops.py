@@ -159,6 +159,18 @@ def fp8_linear(x, w_q, w_scale, bias=None):
     return o.view(*shp[:-1], w_q.shape[0])
 
 
+def fp8_linear_static(x, w_q, w_scale, input_scale, bias=None):
+    """apply_fp8_linear with a calibrated per-tensor activation scale
+    (python/sglang/srt/layers/quantization/fp8_utils.py:1234-1240): static_quant_fp8
+    (fp8_kernel.py:607-700: q = clamp(x * (1/s))) with the scale repeated per token, then
+    fp8_scaled_mm."""
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    q, s = per_tensor_quant_fp8(x2, input_scale)
+    o = fp8_scaled_mm(q, w_q, s.expand(x2.shape[0]).contiguous(), w_scale, bias, x.dtype)
+    return o.view(*shp[:-1], w_q.shape[0])
+
+
 def fp8_block_linear(x, w_q, w_scale_inv, bias=None, block=128):
     """cutlass_w8a8_block_fp8_linear_with_fallback (fp8_utils.py:518-548):
     per_token_group_quant_fp8(x,128) -> fp8_blockwise_scaled_mm -> output += bias (bf16 add)."""

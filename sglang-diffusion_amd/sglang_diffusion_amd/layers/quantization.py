@@ -223,8 +223,7 @@ class Fp8LinearMethod(LinearMethodBase):
         self.quant_config = quant_config
         self.cutlass_fp8_supported = True  # per-token x per-channel GEMM is available
         self.block_quant = quant_config.weight_block_size is not None
-        if quant_config.activation_scheme != "dynamic":
-            raise NotImplementedError("static activation scales are not built for the DiT path")
+        self.static_act = quant_config.activation_scheme == "static"
 
     def create_weights(self, layer, input_size_per_partition, output_partition_sizes, input_size,
                        output_size, params_dtype, **extra_weight_attrs):
@@ -254,7 +253,17 @@ class Fp8LinearMethod(LinearMethodBase):
                                   requires_grad=False)
                 layer.register_parameter("weight_scale", scale)
             set_weight_attrs(scale, extra_weight_attrs)
-        layer.register_parameter("input_scale", None)
+        if self.static_act:
+            # one calibrated activation scale per logical shard (fp8.py:284-298)
+            if not serialized:
+                raise ValueError("static activation scales come from an fp8-serialised checkpoint")
+            iscale = Parameter(torch.full((len(output_partition_sizes),),
+                                          torch.finfo(torch.float32).min, dtype=torch.float32),
+                               requires_grad=False)
+            set_weight_attrs(iscale, extra_weight_attrs)
+            layer.register_parameter("input_scale", iscale)
+        else:
+            layer.register_parameter("input_scale", None)
 
     def process_weights_after_loading(self, layer: nn.Module) -> None:
         if self.block_quant:
@@ -283,7 +292,12 @@ class Fp8LinearMethod(LinearMethodBase):
                 ws = torch.cat([ws[i].expand(wd) for i, wd in enumerate(layer.logical_widths)])
             layer.weight = Parameter(layer.weight.data.contiguous(), requires_grad=False)
             layer.weight_scale = Parameter(ws.float().contiguous(), requires_grad=False)
-        layer.input_scale = None
+        if self.static_act:
+            # the shards share one activation: keep the largest scale (fp8.py:423-433)
+            layer.input_scale = Parameter(layer.input_scale.data.float().max().reshape(1),
+                                          requires_grad=False)
+        else:
+            layer.input_scale = None
 
     def apply(self, layer, x, bias=None) -> torch.Tensor:
         if x.dtype != torch.bfloat16:
@@ -304,6 +318,15 @@ class Fp8LinearMethod(LinearMethodBase):
                                        (ws.stride(1), ws.stride(0)))
             if bias is not None:
                 out += bias  # `output += bias` after the bf16 cast (fp8_utils.py:546-548)
+        elif layer.input_scale is not None:
+            # static per-tensor scale: q = clamp(x * (1/s)), the scale repeated per token for
+            # the per-token x per-channel GEMM (static_quant_fp8(..., repeat_scale=True),
+            # srt/layers/quantization/fp8_kernel.py:607-700, fp8_utils.py:1234-1240)
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            _C.per_tensor_quant_fp8(x2, q, layer.input_scale, True)
+            xs = layer.input_scale.expand(M).contiguous()
+            _C.fp8_scaled_mm(q, layer.weight, xs, layer.weight_scale, bias, out)
         else:
             xs = torch.empty((M,), dtype=torch.float32, device=x.device)
             _C.per_token_quant_fp8(x2, q, xs)

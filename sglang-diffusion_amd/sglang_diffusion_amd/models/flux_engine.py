@@ -57,6 +57,10 @@ class _Packed:
     the weight as long as every member's N is a multiple of 128."""
 
     def __init__(self, lins: List):
+        if any(getattr(l, "input_scale", None) is not None for l in lins):
+            raise NotImplementedError(
+                "the fused schedule quantises activations per token (dynamic scheme); a "
+                "checkpoint with static activation scales runs on the layer path")
         self.fp8 = _is_fp8(lins[0])
         self.block = _is_block(lins[0])
         assert all(_is_fp8(l) == self.fp8 and _is_block(l) == self.block for l in lins)

@@ -239,19 +239,19 @@ def test_converter_matches_oracle_and_model_layout_cpu(tmp_path):
 
 
 # ------------------------------------------------------------------------- on the GPU --
-def _run(model, cfg, device, seed=3):
+def _run(model, cfg, device, seed=3, fused=None):
+    """(module output, fused output); fused=False / True runs only that path."""
     from sglang_diffusion_amd.runtime import pipeline_config as pc
 
     B, Hpx, Wpx, Tt = 2, 96, 64, 16
     Ti = (Hpx // 16) * (Wpx // 16)
     hid, enc, pooled, t, guid = small_inputs(B, Ti, Tt, cfg, seed=seed)
     fr = pc.get_freqs_cis(Tt, Wpx, Hpx, device, model.rotary_emb)
+    args = (hid.to(device), enc.to(device), pooled.to(device), t.to(device), guid.to(device), fr)
     with torch.no_grad():
-        a = model(hid.to(device), enc.to(device), pooled.to(device), t.to(device),
-                  guid.to(device), fr).clone()
-        b = model.forward_fused(hid.to(device), enc.to(device), pooled.to(device), t.to(device),
-                                guid.to(device), fr).clone()
-    return a, b
+        if fused is not None:
+            return ((model.forward_fused if fused else model)(*args).clone(),)
+        return model(*args).clone(), model.forward_fused(*args).clone()
 
 
 @pytest.mark.gpu
@@ -339,6 +339,56 @@ def test_loaded_per_tensor_fp8_checkpoint(device, tmp_path):
     want = O.fp8_linear(x, state[name + ".weight"], lin.weight_scale.cpu(), bias)
     # same rounding points, different fp32 summation order inside the GEMM
     assert_close_bf16(y.cpu(), want, rel=1e-3, max_ulps=1.0, what="per-tensor fp8 linear")
+
+
+@pytest.mark.gpu
+def test_loaded_static_activation_scheme_checkpoint(device, tmp_path):
+    """activation_scheme = "static": every quantised layer carries a calibrated per-tensor
+    `input_scale` beside its per-tensor `weight_scale`; activations are quantised with that
+    fixed scale (values beyond 448 * scale saturate) instead of per token."""
+    from oracle import ops as O
+
+    cfg, plain = _plain_state()
+    qc = Fp8Config(is_checkpoint_fp8_serialized=True, activation_scheme="static")
+    shell = FluxTransformer2DModel(cfg, quant_config=qc)
+    state = {}
+    for name, p in shell.named_parameters():
+        if name.endswith(".weight_scale") or name.endswith(".input_scale"):
+            continue
+        if p.dtype == torch.float8_e4m3fn:
+            w = plain[name].float()
+            s = w.abs().max().clamp_min(1e-12) / 448.0
+            state[name] = (w / s).clamp(-448, 448).to(torch.float8_e4m3fn)
+            state[name[:-len("weight")] + "weight_scale"] = s.reshape(())
+            # a "calibrated" range of 3: most of a unit-variance activation, the tail saturates
+            state[name[:-len("weight")] + "input_scale"] = torch.tensor(3.0 / 448.0)
+        else:
+            state[name] = plain[name]
+    assert any(k.endswith(".input_scale") for k in state)
+    L.save_flux_checkpoint(str(tmp_path), cfg, state, quantization_config={
+        "quant_method": "fp8", "activation_scheme": "static"})
+    model, rep = L.load_flux_transformer(str(tmp_path), device=device, strict=True)
+    assert rep.unexpected_keys == []
+    lin = model.single_transformer_blocks[0].proj_mlp
+    name = next(n for n, m in model.named_modules() if m is lin)
+    assert lin.input_scale.shape == (1,) and lin.input_scale.dtype == torch.float32
+    assert torch.equal(lin.input_scale.cpu(), state[name + ".input_scale"].reshape(1))
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(40, lin.weight.shape[1], generator=g).bfloat16()
+    x[3, 5] = 7.5   # beyond the calibrated range: must saturate at 448 * scale = 3
+    y, _ = lin(x.to(device))
+    bias = lin.bias.detach().cpu() if lin.bias is not None else None
+    want = O.fp8_linear_static(x, state[name + ".weight"], lin.weight_scale.cpu(),
+                               lin.input_scale.cpu(), bias)
+    assert_close_bf16(y.cpu(), want, rel=1e-3, max_ulps=1.0, what="static-scale fp8 linear")
+    # and it is NOT what the dynamic scheme would give
+    dyn = O.fp8_linear(x, state[name + ".weight"], lin.weight_scale.cpu(), bias)
+    assert (y.cpu().float() - dyn.float()).abs().max() > 1e-2
+    # the whole forward runs on the layer path; the fused schedule says why it does not
+    outs = _run(model, cfg, device, fused=False)
+    assert all(torch.isfinite(o.float()).all() for o in outs)
+    with pytest.raises(NotImplementedError, match="static activation"):
+        _run(model, cfg, device, fused=True)
 
 
 @pytest.mark.gpu
