@@ -38,7 +38,8 @@ const char* mi355_last_error(void);
  *    mi355_bf16_to_f16 were added.
  * 3: mi355_linear_args gained block_scale and the four scale strides;
  *    mi355_layernorm_modulate_group_quant and mi355_merge_attn_states were added.
- * 4: mi355_flash_attn_fwd_ex was added; mi355_qk_norm_rope accepts q == NULL. */
+ * 4: mi355_flash_attn_fwd_ex was added; mi355_qk_norm_rope accepts q == NULL.
+ * 5: mi355_cfg_normalize and mi355_guidance_rescale were added. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -294,6 +295,22 @@ int mi355_euler_step(void* out, const void* sample, const void* v, float sigma,
  *   out = bf16(u + bf16(s * bf16(c - u))). */
 int mi355_cfg_combine(void* out, const void* cond, const void* uncond, float scale,
                       int64_t n, void* stream);
+
+/* The two optional steps the reference applies to the combined prediction
+ *   (pipelines_core/stages/denoising.py:1490-1506, rescale_noise_cfg :1164-1191), in place on
+ *   `noise`; both read whole-tensor moments first, gathered through `scratch` (device, fp32,
+ *   16-byte aligned, MI355_CFG_SCRATCH_FLOATS(batch) elements; contents need no initialisation).
+ * cfg_normalize: if ||noise||_2 > factor * ||cond||_2 (norms over the WHOLE tensor, fp32)
+ *   noise = bf16(noise * bf16(factor * ||cond|| / ||noise||)).  factor <= 0: no-op.  No host
+ *   synchronisation: the comparison happens on the device.
+ * guidance_rescale: per sample, with unbiased stds rounded to bf16 as eager does,
+ *   noise = bf16( bf16(g * bf16(noise * bf16(std(cond) / std(noise)))) + bf16((1 - g) * noise) ).
+ *   g <= 0: no-op.  n and per_sample must be multiples of 8. */
+#define MI355_CFG_SCRATCH_FLOATS(batch) (256 * (int64_t)(batch))
+int mi355_cfg_normalize(void* noise, const void* cond, float factor, int64_t n, float* scratch,
+                        void* stream);
+int mi355_guidance_rescale(void* noise, const void* cond, float guidance_rescale, int64_t batch,
+                           int64_t per_sample, float* scratch, void* stream);
 
 /* Every option of the attention kernel in one argument block; the two entry points above are
  * this call with v_is_f16 = 0 / 1 and no query transform.

@@ -223,8 +223,10 @@ def flux_schedule(num_steps: int, height: int, width: int):
 
 def denoise(model: FluxOracle, latents, prompt_embeds, pooled, *, height, width, num_steps,
             embedded_cfg_scale=3.5, neg_embeds=None, neg_pooled=None, guidance_scale=1.0,
-            run_steps: Optional[int] = None):
-    """DenoisingStage.forward with serial CFG."""
+            run_steps: Optional[int] = None, cfg_normalization: float = 0.0,
+            guidance_rescale: float = 0.0):
+    """DenoisingStage.forward with serial CFG (and its two optional post-combine steps,
+    pipelines_core/stages/denoising.py:1490-1506)."""
     sigmas, timesteps = flux_schedule(num_steps, height, width)
     B = latents.shape[0]
     guidance = None
@@ -240,6 +242,9 @@ def denoise(model: FluxOracle, latents, prompt_embeds, pooled, *, height, width,
         if do_cfg:
             uncond = model.forward(x, neg_embeds, neg_pooled, t, guidance, freqs)
             noise = ops.cfg_combine(cond, uncond, guidance_scale)
+            noise = ops.cfg_normalize(noise, cond, cfg_normalization)
+            if guidance_rescale > 0.0:
+                noise = ops.rescale_noise_cfg(noise, cond, guidance_rescale)
         else:
             noise = cond
         latents = ops.euler_step(latents, noise, sigmas[i].item(), sigmas[i + 1].item())

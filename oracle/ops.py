@@ -358,3 +358,28 @@ def euler_step(sample, model_output, sigma: float, sigma_next: float):
 def cfg_combine(cond, uncond, scale: float):
     """Serial CFG (pipelines_core/stages/denoising.py:1486-1488)."""
     return uncond + scale * (cond - uncond)
+
+
+def cfg_normalize(noise_pred, noise_pred_cond, factor: float):
+    """Norm cap after the combine (pipelines_core/stages/denoising.py:1490-1500): norms in fp32
+    over the whole tensor; the 0-dim fp32 rescale factor multiplies the bf16 tensor.  On the
+    device, where the reference runs this, eager casts a 0-dim TENSOR operand to the result
+    dtype (bf16) before multiplying, whichever side it is on; CPU eager does that only when
+    the 0-dim operand comes first (tools/probes/eager_zero_dim.py prints both) -- hence the
+    operand order below, which is the only departure from the reference's text."""
+    if not factor or float(factor) <= 0:
+        return noise_pred
+    ori_norm = torch.linalg.vector_norm(noise_pred_cond.float())
+    new_norm = torch.linalg.vector_norm(noise_pred.float())
+    max_norm = ori_norm * float(factor)
+    if new_norm > max_norm:
+        noise_pred = (max_norm / new_norm) * noise_pred
+    return noise_pred
+
+
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale: float = 0.0):
+    """DenoisingStage.rescale_noise_cfg (pipelines_core/stages/denoising.py:1164-1191)."""
+    std_text = noise_pred_text.std(dim=list(range(1, noise_pred_text.ndim)), keepdim=True)
+    std_cfg = noise_cfg.std(dim=list(range(1, noise_cfg.ndim)), keepdim=True)
+    noise_pred_rescaled = noise_cfg * (std_text / std_cfg)
+    return guidance_rescale * noise_pred_rescaled + (1 - guidance_rescale) * noise_cfg

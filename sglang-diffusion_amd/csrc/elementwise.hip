@@ -769,6 +769,154 @@ extern "C" int mi355_cfg_combine(void* out, const void* cond, const void* uncond
   return MI355_OK;
 }
 
+// ---- optional steps after the CFG combine: norm cap and std rescale -------------------
+// Both need whole-tensor / whole-sample moments first.  moments_kernel leaves, per sample,
+// CFG_MOMENT_BLOCKS partial (sum a, sum a^2, sum b, sum b^2) quadruples in the caller's
+// scratch; the apply kernels fold them in double, in block order (deterministic), and every
+// block derives the same factors from them.
+namespace {
+constexpr int CFG_MOMENT_BLOCKS = 64;
+
+__global__ __launch_bounds__(256) void moments_kernel(const unsigned short* __restrict__ a,
+                                                      const unsigned short* __restrict__ b,
+                                                      int64_t per_sample,
+                                                      float* __restrict__ scratch) {
+  const int64_t base = (int64_t)blockIdx.y * per_sample;
+  const int64_t nvec = per_sample >> 3;
+  float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec;
+       i += (int64_t)CFG_MOMENT_BLOCKS * 256) {
+    float fa[8], fb[8];
+    unpack8(reinterpret_cast<const u32x4*>(a + base)[i], fa);
+    unpack8(reinterpret_cast<const u32x4*>(b + base)[i], fb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sa += fa[j];
+      qa = fmaf(fa[j], fa[j], qa);
+      sb += fb[j];
+      qb = fmaf(fb[j], fb[j], qb);
+    }
+  }
+  __shared__ float red[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  sa = group_sum<64>(sa);
+  qa = group_sum<64>(qa);
+  sb = group_sum<64>(sb);
+  qb = group_sum<64>(qb);
+  if (lane == 0) {
+    red[wave][0] = sa;
+    red[wave][1] = qa;
+    red[wave][2] = sb;
+    red[wave][3] = qb;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                    red[3][threadIdx.x];
+    scratch[((int64_t)blockIdx.y * CFG_MOMENT_BLOCKS + blockIdx.x) * 4 + threadIdx.x] = v;
+  }
+}
+
+// moments of sample `s` from the partials: m[0..3] = sum a, sum a^2, sum b, sum b^2
+__device__ __forceinline__ void fold_moments(const float* scratch, int64_t s, double m[4]) {
+  m[0] = m[1] = m[2] = m[3] = 0.0;
+  for (int k = 0; k < CFG_MOMENT_BLOCKS; ++k) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (s * CFG_MOMENT_BLOCKS + k) * 4);
+    m[0] += v[0];
+    m[1] += v[1];
+    m[2] += v[2];
+    m[3] += v[3];
+  }
+}
+
+// a = cond, b = noise (one "sample" = the whole tensor): cap ||noise|| at factor * ||cond||
+__global__ __launch_bounds__(256) void cfg_normalize_apply_kernel(
+    unsigned short* __restrict__ noise, const float* __restrict__ scratch, float factor,
+    int64_t n) {
+  double m[4];
+  fold_moments(scratch, 0, m);
+  const float ori = sqrtf((float)m[1]), cur = sqrtf((float)m[3]);
+  const float cap = ori * factor;
+  if (!(cur > cap)) return;
+  const float sc = rbf(cap / cur);  // the 0-dim factor takes the tensor's dtype in eager
+  const int64_t nvec = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * 256) {
+    float f[8];
+    unpack8(reinterpret_cast<const u32x4*>(noise)[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= sc;
+    reinterpret_cast<u32x4*>(noise)[i] = pack8(f);
+  }
+}
+
+// a = cond, b = noise, per sample: noise <- g * (noise * (std_a / std_b)) + (1 - g) * noise
+// with eager's bf16 rounding after the stds, the ratio, and each product
+__global__ __launch_bounds__(256) void guidance_rescale_apply_kernel(
+    unsigned short* __restrict__ noise, const float* __restrict__ scratch, float g, float one_m_g,
+    int64_t per_sample) {
+  double m[4];
+  fold_moments(scratch, blockIdx.y, m);
+  const double n = (double)per_sample;
+  const double var_a = (m[1] - m[0] * m[0] / n) / (n - 1.0);
+  const double var_b = (m[3] - m[2] * m[2] / n) / (n - 1.0);
+  const float std_a = rbf((float)sqrt(var_a > 0.0 ? var_a : 0.0));
+  const float std_b = rbf((float)sqrt(var_b > 0.0 ? var_b : 0.0));
+  const float ratio = rbf(std_a / std_b);
+  unsigned short* x = noise + (int64_t)blockIdx.y * per_sample;
+  const int64_t nvec = per_sample >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * 256) {
+    float f[8];
+    unpack8(reinterpret_cast<const u32x4*>(x)[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = rbf(g * rbf(f[j] * ratio)) + rbf(one_m_g * f[j]);
+    reinterpret_cast<u32x4*>(x)[i] = pack8(f);
+  }
+}
+}  // namespace
+
+extern "C" int mi355_cfg_normalize(void* noise, const void* cond, float factor, int64_t n,
+                                   float* scratch, void* stream) {
+  MI355_REQUIRE(noise && cond && scratch, "cfg_normalize: null pointer");
+  MI355_REQUIRE(n >= 0 && n % 8 == 0, "cfg_normalize: n must be a multiple of 8");
+  MI355_REQUIRE(((uintptr_t)noise % 16) == 0 && ((uintptr_t)cond % 16) == 0 &&
+                    ((uintptr_t)scratch % 16) == 0,
+                "cfg_normalize: pointers must be 16-byte aligned");
+  if (n == 0 || !(factor > 0.f)) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(moments_kernel, dim3(CFG_MOMENT_BLOCKS, 1), dim3(256), 0, st,
+                     (const unsigned short*)cond, (const unsigned short*)noise, n, scratch);
+  hipLaunchKernelGGL(cfg_normalize_apply_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st,
+                     (unsigned short*)noise, (const float*)scratch, factor, n);
+  MI355_CHECK_LAUNCH("cfg_normalize");
+  return MI355_OK;
+}
+
+extern "C" int mi355_guidance_rescale(void* noise, const void* cond, float guidance_rescale,
+                                      int64_t batch, int64_t per_sample, float* scratch,
+                                      void* stream) {
+  MI355_REQUIRE(noise && cond && scratch, "guidance_rescale: null pointer");
+  MI355_REQUIRE(batch >= 0 && batch < 65536 && per_sample >= 8 && per_sample % 8 == 0,
+                "guidance_rescale: batch < 65536 and per_sample a multiple of 8");
+  MI355_REQUIRE(((uintptr_t)noise % 16) == 0 && ((uintptr_t)cond % 16) == 0 &&
+                    ((uintptr_t)scratch % 16) == 0,
+                "guidance_rescale: pointers must be 16-byte aligned");
+  if (batch == 0 || !(guidance_rescale > 0.f)) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(moments_kernel, dim3(CFG_MOMENT_BLOCKS, (unsigned)batch), dim3(256), 0, st,
+                     (const unsigned short*)cond, (const unsigned short*)noise, per_sample,
+                     scratch);
+  // (1 - g) is formed in double by the Python expression and reaches the kernel as fp32
+  const float one_m_g = (float)(1.0 - (double)guidance_rescale);
+  hipLaunchKernelGGL(guidance_rescale_apply_kernel,
+                     dim3(grid_for(per_sample / 8 + 1, 256, 256), (unsigned)batch), dim3(256), 0,
+                     st, (unsigned short*)noise, (const float*)scratch, guidance_rescale, one_m_g,
+                     per_sample);
+  MI355_CHECK_LAUNCH("guidance_rescale");
+  return MI355_OK;
+}
+
 // ---- bf16 -> half (V operand of the half-precision P.V attention) --------------------
 namespace {
 __global__ __launch_bounds__(256) void bf16_to_f16_kernel(const unsigned short* __restrict__ x,

@@ -129,13 +129,15 @@ SIGNATURES = {
     "mi355_timestep_embedding": (_int, [_ptr, _ptr, _i64, _i64, _int, _f32, _f32, _f32, _int, _ptr]),
     "mi355_euler_step": (_int, [_ptr, _ptr, _ptr, _f32, _f32, _i64, _ptr]),
     "mi355_cfg_combine": (_int, [_ptr, _ptr, _ptr, _f32, _i64, _ptr]),
+    "mi355_cfg_normalize": (_int, [_ptr, _ptr, _f32, _i64, _ptr, _ptr]),
+    "mi355_guidance_rescale": (_int, [_ptr, _ptr, _f32, _i64, _i64, _ptr, _ptr]),
 }
 
 _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def load_library() -> ctypes.CDLL:
@@ -534,4 +536,39 @@ def cfg_combine(out, cond, uncond, scale: float) -> None:
             _stream(cond),
         ),
         "cfg_combine",
+    )
+
+
+def _cfg_scratch(noise) -> torch.Tensor:
+    return torch.empty(256 * max(1, noise.shape[0]), dtype=torch.float32, device=noise.device)
+
+
+def cfg_normalize(noise, cond, factor: float, scratch=None) -> None:
+    """In place on `noise` (contiguous bf16): cap its global L2 norm at factor * ||cond||."""
+    if not (noise.is_contiguous() and cond.is_contiguous()) or noise.shape != cond.shape:
+        raise RuntimeError("cfg_normalize: contiguous tensors of one shape expected")
+    scratch = _cfg_scratch(noise) if scratch is None else scratch
+    _check(
+        load_library().mi355_cfg_normalize(
+            noise.data_ptr(), cond.data_ptr(), float(factor), noise.numel(), scratch.data_ptr(),
+            _stream(noise),
+        ),
+        "cfg_normalize",
+    )
+
+
+def guidance_rescale(noise, cond, rescale: float, scratch=None) -> None:
+    """In place on `noise` [B, ...] (contiguous bf16): rescale_noise_cfg of the reference."""
+    if not (noise.is_contiguous() and cond.is_contiguous()) or noise.shape != cond.shape:
+        raise RuntimeError("guidance_rescale: contiguous tensors of one shape expected")
+    B = noise.shape[0]
+    scratch = _cfg_scratch(noise) if scratch is None else scratch
+    if scratch.numel() < 256 * B:
+        raise RuntimeError("guidance_rescale: scratch needs 256 floats per sample")
+    _check(
+        load_library().mi355_guidance_rescale(
+            noise.data_ptr(), cond.data_ptr(), float(rescale), B, noise.numel() // max(B, 1),
+            scratch.data_ptr(), _stream(noise),
+        ),
+        "guidance_rescale",
     )

@@ -35,6 +35,8 @@ class Req:
     num_inference_steps: int = 50
     guidance_scale: float = 1.0                # true CFG scale (Flux default 1.0 = off)
     embedded_cfg_scale: float = pc.EMBEDDED_CFG_SCALE
+    cfg_normalization: float = 0.0             # > 0: cap ||noise|| at this factor * ||cond||
+    guidance_rescale: float = 0.0              # > 0: std rescale of the combined prediction
     request_ids: List[Any] = field(default_factory=list)
 
     @property
@@ -108,7 +110,16 @@ class DenoisingStage:
                     encoder_hidden_states=batch.negative_prompt_embeds if neg else batch.prompt_embeds,
                     pooled_projections=batch.neg_pooled_embeds if neg else batch.pooled_embeds,
                     timestep=timestep, guidance=guidance, freqs_cis=freqs).clone()
-                return cfg_parallel_combine(mine, float(batch.guidance_scale), self.cfg_group)
+                noise_pred = cfg_parallel_combine(mine, float(batch.guidance_scale), self.cfg_group)
+                if self._wants_post_cfg(batch):
+                    # the reference broadcasts rank 0's norm / std scalars (denoising.py:
+                    # 1448-1478); here rank 0's conditional prediction itself travels (2 MB), so
+                    # both ranks run the same two kernels on the same operands
+                    cond = mine if not neg else torch.empty_like(mine)
+                    dist.broadcast(cond, src=dist.get_global_rank(self.cfg_group, 0),
+                                   group=self.cfg_group)
+                    self._post_cfg(batch, noise_pred, cond)
+                return noise_pred
             if self.cfg_batched:
                 # cond and uncond of every request ride in ONE forward of batch 2B: rows of a
                 # batch never interact inside the DiT, so this equals two separate passes.
@@ -133,7 +144,21 @@ class DenoisingStage:
                                    guidance=guidance, freqs_cis=freqs).clone()
         noise_pred = torch.empty_like(cond)
         _C.cfg_combine(noise_pred, cond, uncond, float(batch.guidance_scale))
+        self._post_cfg(batch, noise_pred, cond)
         return noise_pred
+
+    @staticmethod
+    def _wants_post_cfg(batch: Req) -> bool:
+        return bool(batch.cfg_normalization and float(batch.cfg_normalization) > 0) or \
+            batch.guidance_rescale > 0.0
+
+    @staticmethod
+    def _post_cfg(batch: Req, noise_pred, cond) -> None:
+        """denoising.py:1490-1506, in place on noise_pred."""
+        if batch.cfg_normalization and float(batch.cfg_normalization) > 0:
+            _C.cfg_normalize(noise_pred, cond, float(batch.cfg_normalization))
+        if batch.guidance_rescale > 0.0:
+            _C.guidance_rescale(noise_pred, cond, float(batch.guidance_rescale))
 
     @torch.no_grad()
     def forward(self, batch: Req, num_steps: Optional[int] = None) -> Req:

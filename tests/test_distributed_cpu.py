@@ -261,3 +261,47 @@ def _cfg_parallel_case(rank):
 def test_cfg_parallel_combine_two_ranks():
     ret = _run(_cfg_parallel_case)
     assert ret[0] and ret[1]
+
+
+def _cfg_parallel_stage_case(rank):
+    """DenoisingStage.predict_noise_with_cfg on a 2-rank CFG group with the norm cap and the
+    std rescale requested: rank 0's conditional prediction is broadcast so both ranks apply
+    the two steps to identical operands.  The device kernels are replaced by the oracle's
+    statements of them (no GPU here); the stage's control flow and collectives are what runs."""
+    from oracle import ops
+    from sglang_diffusion_amd import _C
+    from sglang_diffusion_amd.runtime import denoise as D
+    from sglang_diffusion_amd.runtime import parallel as P
+
+    _C.cfg_normalize = lambda n, c, f, scratch=None: n.copy_(ops.cfg_normalize(n, c, f))
+    _C.guidance_rescale = lambda n, c, r, scratch=None: n.copy_(ops.rescale_noise_cfg(n, c, r))
+    P._hip_scale = lambda x, a: a * x
+    g = torch.Generator().manual_seed(11)
+    cond = torch.randn(2, 32, 8, generator=g).bfloat16()
+    uncond = (torch.randn(2, 32, 8, generator=g) * 0.9).bfloat16()
+    pos, neg = torch.zeros(2, 4, 8), torch.ones(2, 4, 8)
+
+    class FakeDiT:
+        class config:
+            guidance_embeds = False
+
+        def forward_fused(self, hidden_states, encoder_hidden_states, **kw):
+            return (cond if encoder_hidden_states.sum() == 0 else uncond).clone()
+
+    req = D.Req(latents=torch.zeros(2, 32, 8).bfloat16(), prompt_embeds=pos,
+                pooled_embeds=torch.zeros(2, 4), negative_prompt_embeds=neg,
+                neg_pooled_embeds=torch.zeros(2, 4), guidance_scale=4.0, cfg_normalization=1.0,
+                guidance_rescale=0.7)
+    stage = D.DenoisingStage(FakeDiT(), fused=True, cfg_group=dist.group.WORLD)
+    out = stage.predict_noise_with_cfg(req, req.latents, torch.zeros(2), None, None, 0)
+    want = 4.0 * cond + (1 - 4.0) * uncond
+    want = ops.rescale_noise_cfg(ops.cfg_normalize(want, cond, 1.0), cond, 0.7)
+    plain = D.DenoisingStage(FakeDiT(), fused=True, cfg_group=dist.group.WORLD)
+    req.cfg_normalization, req.guidance_rescale = 0.0, 0.0
+    out_plain = plain.predict_noise_with_cfg(req, req.latents, torch.zeros(2), None, None, 0)
+    return torch.equal(out, want), torch.equal(out_plain, 4.0 * cond + (1 - 4.0) * uncond)
+
+
+def test_cfg_parallel_stage_with_post_combine_steps():
+    ret = _run(_cfg_parallel_stage_case)
+    assert ret[0] == (True, True) and ret[1] == (True, True)

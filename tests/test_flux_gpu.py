@@ -113,6 +113,36 @@ def test_denoise_loop_vs_oracle(device, fp8, true_cfg):
         assert torch.equal(out2, out)
 
 
+def test_denoise_loop_with_cfg_normalization_and_guidance_rescale(device):
+    """True CFG followed by the reference's two optional post-combine steps (norm cap, std
+    rescale), 3 steps against the oracle's literal restatement of them."""
+    from oracle import flux_oracle
+    from sglang_diffusion_amd.runtime.denoise import DenoisingStage
+    from sglang_diffusion_amd.runtime.synthetic import make_synthetic_request
+
+    model, state, cfg = build_small(device, fp8=False)
+    oracle = build_oracle(state, cfg, False)
+    req = make_synthetic_request(2, height=96, width=128, num_inference_steps=3, device="cpu",
+                                 seed=9, true_cfg=True, text_len=24,
+                                 joint_dim=cfg.joint_attention_dim,
+                                 pooled_dim=cfg.pooled_projection_dim)
+    req.cfg_normalization, req.guidance_rescale = 1.0, 0.7
+    kw = dict(height=96, width=128, num_steps=3, neg_embeds=req.negative_prompt_embeds,
+              neg_pooled=req.neg_pooled_embeds, guidance_scale=req.guidance_scale)
+    ref = flux_oracle.denoise(oracle, req.latents.clone(), req.prompt_embeds, req.pooled_embeds,
+                              cfg_normalization=1.0, guidance_rescale=0.7, **kw)
+    plain = flux_oracle.denoise(oracle, req.latents.clone(), req.prompt_embeds, req.pooled_embeds,
+                                **kw)
+    assert rel_l2(ref, plain) > 1e-2, "the two options must matter in this set-up"
+    for name in ("latents", "prompt_embeds", "pooled_embeds", "negative_prompt_embeds",
+                 "neg_pooled_embeds"):
+        setattr(req, name, getattr(req, name).to(device))
+    out = DenoisingStage(model, fused=True).forward(req).latents
+    e = rel_l2(out, ref)
+    print(f"denoise with cfg_normalization + guidance_rescale: rel {e:.2e}")
+    assert e <= TOL_BF16 * 3.5
+
+
 def test_batch_rows_are_independent_at_flux_shapes(device):
     """Size-independent property at the real sequence length (S = 512 + 4096) on a 1+1-block
     model of the real width: a sample's output does not depend on what else is in the batch,

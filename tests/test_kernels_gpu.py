@@ -632,3 +632,44 @@ def test_euler_step_and_cfg_bit_exact(device):
     out = torch.empty_like(lat, device=device)
     _C.cfg_combine(out, lat.to(device), v.to(device), 3.5)
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,T,C", [(4, 4096, 64), (1, 96, 64), (3, 1000, 8)])
+def test_cfg_normalize_and_guidance_rescale_vs_oracle(device, B, T, C):
+    """The optional steps after the CFG combine.  Norms / stds are sums over up to 1M
+    elements: the device's summation order is not eager's, so a factor can land on the other
+    side of a bf16 rounding once in a while -- bit-equal in all but a tiny fraction of
+    elements, never more than one ulp apart."""
+    cond = torch.randn(B, T, C, generator=g(201)).bfloat16()
+    uncond = (torch.randn(B, T, C, generator=g(202)) * 0.9 + 0.05).bfloat16()
+    noise = ops.cfg_combine(cond, uncond, 4.0)          # norm well above cond's
+    # --- norm cap: active, then inactive (factor large enough), then disabled
+    for factor, active in ((1.0, True), (0.7, True), (50.0, False), (0.0, False)):
+        ref = ops.cfg_normalize(noise, cond, factor)
+        got = noise.to(device).clone()
+        _C.cfg_normalize(got, cond.to(device), factor)
+        if not active:
+            assert torch.equal(got.cpu(), noise)
+            assert torch.equal(ref, noise)
+        else:
+            assert not torch.equal(ref, noise)
+            assert bf16_ulp_diff(got, ref).max() <= 1 and mismatch_frac(got, ref) < 0.01
+            # the cap holds
+            n_got = torch.linalg.vector_norm(got.float().cpu())
+            assert n_got <= torch.linalg.vector_norm(cond.float()) * factor * 1.01
+    # --- std rescale, per sample
+    for gr in (0.7, 1.0, 0.25):
+        ref = ops.rescale_noise_cfg(noise, cond, gr)
+        got = noise.to(device).clone()
+        _C.guidance_rescale(got, cond.to(device), gr)
+        assert bf16_ulp_diff(got, ref).max() <= 1 and mismatch_frac(got, ref) < 0.01
+    got = noise.to(device).clone()
+    _C.guidance_rescale(got, cond.to(device), 0.0)
+    assert torch.equal(got.cpu(), noise)
+    # samples are independent: sample 0 alone gives sample 0 of the batch
+    if B > 1:
+        full = noise.to(device).clone()
+        _C.guidance_rescale(full, cond.to(device), 0.7)
+        one = noise[:1].to(device).clone()
+        _C.guidance_rescale(one, cond[:1].to(device), 0.7)
+        assert torch.equal(full[:1], one)
