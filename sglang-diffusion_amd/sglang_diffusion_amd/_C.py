@@ -14,7 +14,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355dit.so")
+# MI355_DIT_LIB points at another build of the library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("MI355_DIT_LIB") or os.path.join(_HERE, "libmi355dit.so")
 
 _i64 = ctypes.c_int64
 _f32 = ctypes.c_float
