@@ -18,6 +18,9 @@ Pinning status (see oracle/make_golden.py, tests/test_oracle_pins.py):
   * the diffusers-defined modules (AdaLayerNorm*, FeedForward, embeddings) and
     the scheduler are restated from the call sites; no reference test or
     fixture covers them: parity unpinned for those.
+  * the offline checkpoint quantisers (quantize_weight_block, convert_channel_fp8: the
+    reference's tools/convert_hf_to_fp8.py) are restated from the source text; the reference
+    ships no fixture for them and its Python may not be executed here: parity unpinned.
 """
 
 from __future__ import annotations

@@ -8,9 +8,9 @@ dev = "cuda"; B, S, H, D = 4, 4608, 24, 128
 qkv = torch.randn(B, S, 3, H, D, device=dev).bfloat16()
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
 v16 = _C.value_to_f16(v); o = torch.empty(B, S, H, D, device=dev, dtype=torch.bfloat16)
-for half in (True, False):
+for half in (True, False, True, False):
     vv = v16 if half else v
-    for _ in range(3):
+    for _ in range(15):
         _C.flash_attn_fwd(q, k, vv, o, None, D ** -0.5, False, half)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
