@@ -39,7 +39,8 @@ const char* mi355_last_error(void);
  * 3: mi355_linear_args gained block_scale and the four scale strides;
  *    mi355_layernorm_modulate_group_quant and mi355_merge_attn_states were added.
  * 4: mi355_flash_attn_fwd_ex was added; mi355_qk_norm_rope accepts q == NULL.
- * 5: mi355_cfg_normalize and mi355_guidance_rescale were added. */
+ * 5: mi355_cfg_normalize and mi355_guidance_rescale were added.
+ * 6: mi355_scale_residual_layernorm_modulate was added. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -247,6 +248,17 @@ int mi355_layernorm_modulate(void* out, const void* x, const void* shift,
                              int64_t ldx, int64_t ldo, int64_t ldmod, float eps,
                              const mi355_rowmap* x_map, const mi355_rowmap* o_map,
                              void* stream);
+
+/* ScaleResidualLayerNormScaleShift (layers/layernorm.py:332-443, its native form):
+ *   res_out = bf16(residual + bf16(x * gate[b]))   (gate NULL: res_out = bf16(residual + x))
+ *   out     = the mi355_layernorm_modulate arithmetic on res_out
+ * in one pass over the rows: x, residual, res_out, out are [B*T, dim] with their own row
+ * strides; gate, shift, scale bf16 rows per sample (strides ldg, ldmod).  res_out may alias
+ * residual or x. */
+int mi355_scale_residual_layernorm_modulate(
+    void* out, void* res_out, const void* residual, const void* x, const void* gate,
+    const void* shift, const void* scale, int64_t B, int64_t T, int64_t dim, int64_t ldx,
+    int64_t ldr, int64_t ldo, int64_t ldro, int64_t ldg, int64_t ldmod, float eps, void* stream);
 
 /* Same, then dynamic per-token fp8 quantisation of the bf16 result
  * (mi355_per_token_quant_fp8 semantics): feeds the fp8 linears directly. */

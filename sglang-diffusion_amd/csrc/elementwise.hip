@@ -242,12 +242,21 @@ __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions, u
 // quantiser's arithmetic (absmax floored at 1e-10, q = x / scale, as
 // sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu:25-114); a group is the 16 lanes that hold
 // 128 consecutive channels of one chunk, scales are stored dense as [rows][dim / 128].
-template <int NCH, int QUANT>
+// PRE: the normalised row is first formed as residual + gate[b] * x (both roundings to bf16,
+// gate == nullptr meaning 1) and also written to res_out: ScaleResidualLayerNormScaleShift.
+struct LnPre {
+  const unsigned short* residual;
+  const unsigned short* gate;
+  unsigned short* res_out;
+  int64_t ldr, ldro, ldg;
+};
+
+template <int NCH, int QUANT, bool PRE = false>
 __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     void* __restrict__ out, float* __restrict__ qscale, const unsigned short* __restrict__ x,
     const unsigned short* __restrict__ shift, const unsigned short* __restrict__ scale, int64_t rows,
     int T, int dim, int64_t ldx, int64_t ldo, int64_t ldmod, float eps, mi355_rowmap xm,
-    mi355_rowmap om) {
+    mi355_rowmap om, LnPre pre = LnPre{}) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -262,6 +271,19 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     const int i = c * 64 + lane;
     if (i < nvec) {
       unpack8(xr[i], v[c]);
+      if constexpr (PRE) {
+        float rr[8], gg[8];
+        unpack8(reinterpret_cast<const u32x4*>(pre.residual + row * pre.ldr)[i], rr);
+        if (pre.gate) {
+          unpack8(reinterpret_cast<const u32x4*>(pre.gate + b * pre.ldg)[i], gg);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[c][j] = rbf(rr[j] + rbf(v[c][j] * gg[j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[c][j] = rbf(rr[j] + v[c][j]);
+        }
+        reinterpret_cast<u32x4*>(pre.res_out + row * pre.ldro)[i] = pack8(v[c]);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) sum += v[c][j];
     } else {
@@ -668,6 +690,46 @@ extern "C" int mi355_layernorm_modulate_group_quant(void* q, float* s, const voi
                 (long)dim);
   return launch_ln_mod(q, s, x, shift, scale, B, T, dim, ldx, /*ldo*/ 8, ldmod, eps, x_map,
                        nullptr, 2, stream);
+}
+
+extern "C" int mi355_scale_residual_layernorm_modulate(
+    void* out, void* res_out, const void* residual, const void* x, const void* gate,
+    const void* shift, const void* scale, int64_t B, int64_t T, int64_t dim, int64_t ldx,
+    int64_t ldr, int64_t ldo, int64_t ldro, int64_t ldg, int64_t ldmod, float eps, void* stream) {
+  MI355_REQUIRE(out && res_out && residual && x, "scale_residual_layernorm_modulate: null pointer");
+  MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0 && dim <= 16384,
+                "scale_residual_layernorm_modulate: dim (%ld) must be a multiple of 8 and <= 16384",
+                (long)dim);
+  MI355_REQUIRE(B * T < (1ll << 31), "scale_residual_layernorm_modulate: too many rows");
+  MI355_REQUIRE(ldx % 8 == 0 && ldr % 8 == 0 && ldo % 8 == 0 && ldro % 8 == 0 && ldg % 8 == 0 &&
+                    ldmod % 8 == 0,
+                "scale_residual_layernorm_modulate: row strides must be multiples of 8");
+  for (const void* ptr : {(const void*)out, (const void*)res_out, residual, x, gate, shift, scale})
+    MI355_REQUIRE(((uintptr_t)ptr % 16) == 0,
+                  "scale_residual_layernorm_modulate: pointers must be 16-byte aligned");
+  const int64_t rows = B * T;
+  if (rows == 0) return MI355_OK;
+  const mi355_rowmap id = rowmap_or_identity(nullptr);
+  LnPre pre{(const unsigned short*)residual, (const unsigned short*)gate, (unsigned short*)res_out,
+            ldr, ldro, ldg};
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (int)((dim / 8 + 63) / 64);
+#define LNP(N)                                                                                     \
+  hipLaunchKernelGGL((layernorm_modulate_kernel<N, 0, true>), grid, block, 0, st, out,             \
+                     (float*)nullptr, (const unsigned short*)x, (const unsigned short*)shift,      \
+                     (const unsigned short*)scale, rows, (int)T, (int)dim, ldx, ldo, ldmod, eps,   \
+                     id, id, pre)
+  if (nch <= 1) LNP(1);
+  else if (nch <= 2) LNP(2);
+  else if (nch <= 4) LNP(4);
+  else if (nch <= 6) LNP(6);
+  else if (nch <= 8) LNP(8);
+  else if (nch <= 16) LNP(16);
+  else LNP(32);
+#undef LNP
+  MI355_CHECK_LAUNCH("scale_residual_layernorm_modulate");
+  return MI355_OK;
 }
 
 extern "C" int mi355_gate_residual(void* out, const void* residual, const void* gate,

@@ -109,6 +109,8 @@ SIGNATURES = {
         _int,
         [_ptr] * 4 + [_i64] * 6 + [_f32, ctypes.POINTER(RowMap), ctypes.POINTER(RowMap), _ptr],
     ),
+    "mi355_scale_residual_layernorm_modulate": (
+        _int, [_ptr] * 7 + [_i64] * 9 + [_f32, _ptr]),
     "mi355_layernorm_modulate_quant": (
         _int,
         [_ptr] * 5 + [_i64] * 5 + [_f32, ctypes.POINTER(RowMap), _ptr],
@@ -138,7 +140,7 @@ _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def load_library() -> ctypes.CDLL:
@@ -451,6 +453,23 @@ def layernorm_modulate(out, x, shift, scale, B, T, eps, x_map=None, o_map=None) 
             ctypes.byref(xm) if xm else None, ctypes.byref(om) if om else None, _stream(x),
         ),
         "layernorm_modulate",
+    )
+
+
+def scale_residual_layernorm_modulate(out, res_out, residual, x, gate, shift, scale, B, T,
+                                      eps) -> None:
+    """res_out = residual + gate[b] * x; out = LayerNorm(res_out) * (1 + scale[b]) + shift[b];
+    2-D [B*T, dim] operands (last dim contiguous), gate/shift/scale [B, dim] rows or None."""
+    dim = x.shape[-1]
+    mod = shift if shift is not None else scale
+    _check(
+        load_library().mi355_scale_residual_layernorm_modulate(
+            out.data_ptr(), res_out.data_ptr(), residual.data_ptr(), x.data_ptr(), _p(gate),
+            _p(shift), _p(scale), B, T, dim, x.stride(0), residual.stride(0), out.stride(0),
+            res_out.stride(0), gate.stride(0) if gate is not None else 8,
+            mod.stride(0) if mod is not None else 8, float(eps), _stream(x),
+        ),
+        "scale_residual_layernorm_modulate",
     )
 
 

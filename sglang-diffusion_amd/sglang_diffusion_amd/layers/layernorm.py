@@ -163,3 +163,79 @@ class LayerNormNoAffine(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return layernorm_modulate(x, None, None, self.eps)
+
+
+def _rows_per_sample(t: Optional[torch.Tensor], B: int, D: int, what: str) -> Optional[torch.Tensor]:
+    """[B, D] or [B, 1, D] modulation tensors as [B, D] rows (last dim contiguous)."""
+    if t is None:
+        return None
+    if t.dim() == 3 and t.shape[1] == 1:
+        t = t[:, 0]
+    if t.dim() != 2 or t.shape != (B, D):
+        raise NotImplementedError(f"{what}: expected one [{D}] row per sample, got {tuple(t.shape)} "
+                                  "(per-frame [B, F, 1, D] modulation is not built)")
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+class LayerNormScaleShift(CustomOp):
+    """layers/layernorm.py:450-524 (`_NormScaleShift`, norm_type "layer"): FP32LayerNorm without
+    affine parameters, then normed * (1 + scale) + shift, in one kernel with eager's bf16
+    rounding points (mi355_layernorm_modulate)."""
+
+    norm_type = "layer"
+
+    def __init__(self, hidden_size: int, eps: float = 1e-6, elementwise_affine: bool = False,
+                 dtype: torch.dtype = torch.float32, prefix: str = ""):
+        super().__init__()
+        if elementwise_affine:
+            raise NotImplementedError("LayerNormScaleShift with affine LayerNorm weights is not "
+                                      "built (the DiT blocks use elementwise_affine=False)")
+        self.hidden_size = hidden_size
+        self.eps = eps
+
+    def forward_hip(self, x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+        B, T, D = x.shape
+        return layernorm_modulate(x, _rows_per_sample(shift, B, D, "LayerNormScaleShift"),
+                                  _rows_per_sample(scale, B, D, "LayerNormScaleShift"), self.eps)
+
+
+
+class ScaleResidualLayerNormScaleShift(CustomOp):
+    """layers/layernorm.py:332-443 (`_ScaleResidualNormScaleShift`, norm_type "layer"):
+    residual_out = residual + gate * x, normed = LayerNorm(residual_out),
+    out = normed * (1 + scale) + shift; returns (out, residual_out).  One pass over the rows
+    (mi355_scale_residual_layernorm_modulate); gate is a [B, D] / [B, 1, D] tensor or the int 1."""
+
+    norm_type = "layer"
+
+    def __init__(self, hidden_size: int, eps: float = 1e-6, elementwise_affine: bool = False,
+                 dtype: torch.dtype = torch.float32, prefix: str = ""):
+        super().__init__()
+        if elementwise_affine:
+            raise NotImplementedError("ScaleResidualLayerNormScaleShift with affine LayerNorm "
+                                      "weights is not built")
+        self.hidden_size = hidden_size
+        self.eps = eps
+
+    def forward_hip(self, residual: torch.Tensor, x: torch.Tensor, gate, shift: torch.Tensor,
+                    scale: torch.Tensor):
+        B, T, D = x.shape
+        if isinstance(gate, int):
+            if gate != 1:
+                raise ValueError(f"Only gate value of 1 is supported for int type, but got {gate}")
+            g = None
+        elif isinstance(gate, torch.Tensor):
+            g = _rows_per_sample(gate, B, D, "ScaleResidualLayerNormScaleShift")
+        else:
+            raise ValueError(f"Gate type {type(gate)} not supported")
+        x2, r2 = x.reshape(B * T, D), residual.reshape(B * T, D)
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        r2 = r2 if r2.stride(-1) == 1 else r2.contiguous()
+        out = torch.empty((B * T, D), dtype=x.dtype, device=x.device)
+        res_out = torch.empty((B * T, D), dtype=x.dtype, device=x.device)
+        _C.scale_residual_layernorm_modulate(
+            out, res_out, r2, x2, g,
+            _rows_per_sample(shift, B, D, "ScaleResidualLayerNormScaleShift"),
+            _rows_per_sample(scale, B, D, "ScaleResidualLayerNormScaleShift"), B, T, self.eps)
+        return out.view(B, T, D), res_out.view(B, T, D)
+

@@ -15,9 +15,10 @@ reference's eager ("native") path, every bf16 rounding point kept:
                                        (hunyuanvideo.py:219-228,383-397; rotation formula
                                        jit_kernel/diffusion/triton/rotary.py:43-64)
 
-which are exactly the passes the Flux path already runs (mi355_layernorm_modulate,
-mi355_gate_residual / the GEMM's gate-residual epilogue, mi355_qk_norm_rope), with two
-differences in layout: the joint sequence is [video | text] (Flux: [text | image]) and the text
+which are the passes the Flux path already runs (mi355_layernorm_modulate,
+mi355_gate_residual, mi355_qk_norm_rope) plus the one-pass
+mi355_scale_residual_layernorm_modulate, behind layer classes of the reference's names
+(layers/layernorm.py, layers/elementwise.py here), with two differences in layout: the joint sequence is [video | text] (Flux: [text | image]) and the text
 tokens are not rotated -- the rotation table carries cos = 1, sin = 0 on their rows, which is
 the identity bit for bit.  No fused multi-block schedule exists for this model yet; the blocks
 run layer by layer.
@@ -31,21 +32,11 @@ import torch.nn as nn
 
 from .. import _C
 from ..layers.attention import UlyssesAttention
-from ..layers.layernorm import RMSNorm, _silu, layernorm_modulate
+from ..layers.elementwise import MulAdd
+from ..layers.layernorm import (LayerNormScaleShift, RMSNorm, ScaleResidualLayerNormScaleShift,
+                                _silu)
 from ..layers.linear import ColumnParallelLinear, ReplicatedLinear
 from ..layers.quantization import QuantizationConfig
-
-
-def _gate_residual(residual: torch.Tensor, gate: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """residual + y * gate[:, None] on [B, T, D] with both bf16 roundings."""
-    B, T, D = y.shape
-    y2 = y.reshape(B * T, D)
-    r2 = residual.reshape(B * T, D)
-    y2 = y2 if y2.is_contiguous() else y2.contiguous()
-    r2 = r2 if r2.is_contiguous() else r2.contiguous()
-    out = torch.empty_like(r2)
-    _C.gate_residual(out, r2, gate, y2, B, T)
-    return out.view(B, T, D)
 
 
 def _gelu_tanh(x: torch.Tensor) -> torch.Tensor:
@@ -120,6 +111,10 @@ class MMDoubleStreamBlock(nn.Module):
         for s in ("img", "txt"):
             pre = f"{prefix}.{s}" if s == "img" else ""   # only the image stream is prefixed
             setattr(self, f"{s}_mod", ModulateProjection(hidden_size, factor=6, dtype=dt))
+            setattr(self, f"{s}_attn_norm", LayerNormScaleShift(hidden_size, eps=1e-6, dtype=dt))
+            setattr(self, f"{s}_attn_residual_mlp_norm",
+                    ScaleResidualLayerNormScaleShift(hidden_size, eps=1e-6, dtype=dt))
+            setattr(self, f"{s}_mlp_residual", MulAdd())
             setattr(self, f"{s}_attn_qkv", ReplicatedLinear(
                 hidden_size, hidden_size * 3, bias=True, params_dtype=dt,
                 prefix=f"{pre}_attn_qkv" if pre else "", quant_config=quant_config))
@@ -146,8 +141,8 @@ class MMDoubleStreamBlock(nn.Module):
         Ti, Tt = img.shape[1], txt.shape[1]
 
         # q, k, v of both streams in one joint [video | text] buffer; norm + RoPE in one pass
-        qkv = torch.cat([self._qkv("img", layernorm_modulate(img, i_sh1, i_sc1)),
-                         self._qkv("txt", layernorm_modulate(txt, t_sh1, t_sc1))], dim=1)
+        qkv = torch.cat([self._qkv("img", self.img_attn_norm(img, i_sh1, i_sc1)),
+                         self._qkv("txt", self.txt_attn_norm(txt, t_sh1, t_sc1))], dim=1)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         cos, sin = _joint_rope_table(freqs_cis[0], freqs_cis[1], Tt)
         _C.qk_norm_rope(q, k, self.img_attn_q_norm.weight.data, self.img_attn_k_norm.weight.data,
@@ -160,9 +155,10 @@ class MMDoubleStreamBlock(nn.Module):
         for s, x, attn, g1, sh2, sc2, g2 in (("img", img, img_attn, i_g1, i_sh2, i_sc2, i_g2),
                                              ("txt", txt, txt_attn, t_g1, t_sh2, t_sc2, t_g2)):
             a, _ = getattr(self, f"{s}_attn_proj")(attn.reshape(B, attn.shape[1], -1))
-            resid = _gate_residual(x, g1, a)                       # x + attn_out * gate
-            mlp_out = getattr(self, f"{s}_mlp")(layernorm_modulate(resid, sh2, sc2))
-            out.append(_gate_residual(resid, g2, mlp_out))         # MulAdd(mlp_out, gate, resid)
+            # x + attn_out * gate, LayerNorm, scale / shift: one pass
+            mlp_in, resid = getattr(self, f"{s}_attn_residual_mlp_norm")(x, a, g1, sh2, sc2)
+            mlp_out = getattr(self, f"{s}_mlp")(mlp_in)
+            out.append(getattr(self, f"{s}_mlp_residual")(mlp_out, g2, resid))
         return out[0], out[1]
 
 
@@ -187,6 +183,8 @@ class MMSingleStreamBlock(nn.Module):
                                         quant_config=quant_config)
         self.q_norm = RMSNorm(head_dim, eps=1e-6, dtype=dt)
         self.k_norm = RMSNorm(head_dim, eps=1e-6, dtype=dt)
+        self.input_norm_scale_shift = LayerNormScaleShift(hidden_size, eps=1e-6, dtype=dt)
+        self.output_residual = MulAdd()
         self.modulation = ModulateProjection(hidden_size, factor=3, dtype=dt)
         self.attn = UlyssesAttention(num_heads=num_attention_heads, head_size=head_dim, causal=False,
                                      supported_attention_backends=supported_attention_backends,
@@ -195,7 +193,7 @@ class MMSingleStreamBlock(nn.Module):
     def forward(self, x: torch.Tensor, vec: torch.Tensor, txt_len: int,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
         shift, scale, gate = self.modulation(vec).chunk(3, dim=-1)
-        lin1, _ = self.linear1(layernorm_modulate(x, shift, scale))
+        lin1, _ = self.linear1(self.input_norm_scale_shift(x, shift, scale))
         B, S = lin1.shape[:2]
         D = self.hidden_size
         qkv = lin1[:, :, :3 * D].unflatten(-1, (3, self.num_attention_heads, -1))
@@ -208,7 +206,7 @@ class MMSingleStreamBlock(nn.Module):
         attn = torch.cat((img_o, txt_o), dim=1).reshape(B, S, -1)
         combined = torch.cat((attn, _gelu_tanh(lin1[:, :, 3 * D:])), dim=-1)
         out, _ = self.linear2(combined)
-        return _gate_residual(x, gate, out)                        # MulAdd(output, gate, x)
+        return self.output_residual(out, gate, x)
 
 
 def process_weights_after_loading(module: nn.Module) -> None:

@@ -82,3 +82,43 @@ def test_text_rows_are_not_rotated(device):
     with torch.no_grad():
         out = blk(txt.to(device), vec.to(device), 32, (empty.to(device), empty.to(device)))
     assert rel_l2(out, ref) <= 4e-3
+
+
+def test_fused_norm_layers_match_their_parts_and_the_oracle(device):
+    """LayerNormScaleShift, ScaleResidualLayerNormScaleShift and MulAdd (the reference's layer
+    names and call signatures): the one-pass residual + gate * x -> LayerNorm -> scale / shift
+    kernel gives the bits of the separate gate-residual and norm-modulate kernels, and both
+    agree with the oracle's eager restatement."""
+    from sglang_diffusion_amd.layers.elementwise import MulAdd
+    from sglang_diffusion_amd.layers.layernorm import (LayerNormScaleShift,
+                                                       ScaleResidualLayerNormScaleShift)
+
+    B, T, D = 2, 75, 384
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, D, generator=g).bfloat16()
+    res = torch.randn(B, T, D, generator=g).bfloat16()
+    gate, shift, scale = ((torch.randn(B, D, generator=g) * 0.5).bfloat16() for _ in range(3))
+    O = HunyuanBlocksOracle
+    want_res = O.mul_add(x, gate, res)
+    want_out = O.norm_scale_shift(want_res, shift, scale)
+    d = lambda t: t.to(device)  # noqa: E731
+    norm, fused, muladd = LayerNormScaleShift(D), ScaleResidualLayerNormScaleShift(D), MulAdd()
+    out, res_out = fused(d(res), d(x), d(gate), d(shift), d(scale))
+    # parts: MulAdd then LayerNormScaleShift
+    part_res = muladd(d(x), d(gate), d(res))
+    part_out = norm(part_res, d(shift), d(scale))
+    assert torch.equal(res_out, part_res) and torch.equal(out, part_out)
+    assert torch.equal(res_out.cpu(), want_res)
+    assert rel_l2(out, want_out) <= 1e-3
+    # [B, 1, D] modulation rows and the integer gate of the cross-attention call sites
+    out3, res3 = fused(d(res), d(x), d(gate)[:, None], d(shift)[:, None], d(scale)[:, None])
+    assert torch.equal(out3, out) and torch.equal(res3, res_out)
+    out1, res1 = fused(d(res), d(x), 1, d(shift), d(scale))
+    assert torch.equal(res1.cpu(), res + x)
+    assert torch.equal(out1, norm(res1, d(shift), d(scale)))
+    with pytest.raises(ValueError):
+        fused(d(res), d(x), 2, d(shift), d(scale))
+    with pytest.raises(NotImplementedError):
+        fused(d(res), d(x), d(gate)[:, None, None].expand(B, 3, 1, D), d(shift), d(scale))
+    with pytest.raises(NotImplementedError):
+        LayerNormScaleShift(D, elementwise_affine=True)
