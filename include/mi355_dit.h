@@ -40,7 +40,8 @@ const char* mi355_last_error(void);
  *    mi355_layernorm_modulate_group_quant and mi355_merge_attn_states were added.
  * 4: mi355_flash_attn_fwd_ex was added; mi355_qk_norm_rope accepts q == NULL.
  * 5: mi355_cfg_normalize and mi355_guidance_rescale were added.
- * 6: mi355_scale_residual_layernorm_modulate was added. */
+ * 6: mi355_scale_residual_layernorm_modulate, mi355_layernorm_affine and mi355_token_mean were
+ *    added. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -259,6 +260,19 @@ int mi355_scale_residual_layernorm_modulate(
     void* out, void* res_out, const void* residual, const void* x, const void* gate,
     const void* shift, const void* scale, int64_t B, int64_t T, int64_t dim, int64_t ldx,
     int64_t ldr, int64_t ldo, int64_t ldro, int64_t ldg, int64_t ldmod, float eps, void* stream);
+
+/* torch.nn.LayerNorm with elementwise affine parameters over the last dimension (the token
+ * refiner of the video DiT, models/dits/hunyuanvideo.py:880-905): fp32 statistics,
+ * out = bf16((x - mean) * rstd * weight + bias), one rounding.  weight, bias bf16 [dim]. */
+int mi355_layernorm_affine(void* out, const void* x, const void* weight, const void* bias,
+                           int64_t rows, int64_t dim, int64_t ldx, int64_t ldo, float eps,
+                           void* stream);
+
+/* out[b, :] = bf16(mean over tokens of x[b, t, :]) (torch.mean(x, dim=1),
+ * models/dits/hunyuanvideo.py:849); x [B, T, dim] with strides (x_batch_stride, ldx, 1),
+ * out [B, dim] dense. */
+int mi355_token_mean(void* out, const void* x, int64_t B, int64_t T, int64_t dim, int64_t ldx,
+                     int64_t x_batch_stride, void* stream);
 
 /* Same, then dynamic per-token fp8 quantisation of the bf16 result
  * (mi355_per_token_quant_fp8 semantics): feeds the fp8 linears directly. */

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     void* __restrict__ out, float* __restrict__ qscale, const unsigned short* __restrict__ x,
     const unsigned short* __restrict__ shift, const unsigned short* __restrict__ scale, int64_t rows,
     int T, int dim, int64_t ldx, int64_t ldo, int64_t ldmod, float eps, mi355_rowmap xm,
-    mi355_rowmap om, LnPre pre = LnPre{}) {
+    mi355_rowmap om, LnPre pre = LnPre{}, int affine = 0) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -321,9 +321,15 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
       if (shr) unpack8(shr[i], sh);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float y = rbf((v[c][j] - mean) * rstd);  // LayerNorm output (bf16)
-        if (scr) y = rbf(y * rbf(1.0f + sc[j]));  // * (1 + scale)
-        if (shr) y = rbf(y + sh[j]);              // + shift
+        float y;
+        if (affine) {
+          // nn.LayerNorm with weight (scale row) and bias (shift row): one rounding at the end
+          y = rbf((v[c][j] - mean) * rstd * sc[j] + sh[j]);
+        } else {
+          y = rbf((v[c][j] - mean) * rstd);        // LayerNorm output (bf16)
+          if (scr) y = rbf(y * rbf(1.0f + sc[j]));  // * (1 + scale)
+          if (shr) y = rbf(y + sh[j]);              // + shift
+        }
         v[c][j] = y;
         if constexpr (QUANT == 2) gmax[c] = fmaxf(gmax[c], fabsf(y));
         else amax = fmaxf(amax, fabsf(y));
@@ -729,6 +735,80 @@ extern "C" int mi355_scale_residual_layernorm_modulate(
   else LNP(32);
 #undef LNP
   MI355_CHECK_LAUNCH("scale_residual_layernorm_modulate");
+  return MI355_OK;
+}
+
+extern "C" int mi355_layernorm_affine(void* out, const void* x, const void* weight,
+                                      const void* bias, int64_t rows, int64_t dim, int64_t ldx,
+                                      int64_t ldo, float eps, void* stream) {
+  MI355_REQUIRE(out && x && weight && bias, "layernorm_affine: null pointer");
+  MI355_REQUIRE(rows >= 0 && rows < (1ll << 31) && dim > 0 && dim % 8 == 0 && dim <= 16384,
+                "layernorm_affine: dim (%ld) must be a multiple of 8 and <= 16384", (long)dim);
+  MI355_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+                    ((uintptr_t)out % 16) == 0 && ((uintptr_t)weight % 16) == 0 &&
+                    ((uintptr_t)bias % 16) == 0,
+                "layernorm_affine: rows must be 16-byte aligned");
+  if (rows == 0) return MI355_OK;
+  const mi355_rowmap id = rowmap_or_identity(nullptr);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (int)((dim / 8 + 63) / 64);
+  // T = rows: every row reads modulation row 0, which is the weight / bias vector
+#define LNA(N)                                                                                     \
+  hipLaunchKernelGGL((layernorm_modulate_kernel<N, 0, false>), grid, block, 0, st, out,            \
+                     (float*)nullptr, (const unsigned short*)x, (const unsigned short*)bias,       \
+                     (const unsigned short*)weight, rows, (int)rows, (int)dim, ldx, ldo,           \
+                     (int64_t)0, eps, id, id, LnPre{}, 1)
+  if (nch <= 1) LNA(1);
+  else if (nch <= 2) LNA(2);
+  else if (nch <= 4) LNA(4);
+  else if (nch <= 6) LNA(6);
+  else if (nch <= 8) LNA(8);
+  else if (nch <= 16) LNA(16);
+  else LNA(32);
+#undef LNA
+  MI355_CHECK_LAUNCH("layernorm_affine");
+  return MI355_OK;
+}
+
+namespace {
+// out[b][c] = bf16(mean over t of x[b][t][c]), fp32 sum in token order
+__global__ __launch_bounds__(64) void token_mean_kernel(const unsigned short* __restrict__ x,
+                                                        unsigned short* __restrict__ out, int T,
+                                                        int dim, int64_t ldx, int64_t x_sb) {
+  const int i = blockIdx.x * 64 + threadIdx.x;  // 16-byte vector index inside the row
+  if (i >= (dim >> 3)) return;
+  const unsigned short* xb = x + (int64_t)blockIdx.y * x_sb;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int t = 0; t < T; ++t) {
+    float f[8];
+    unpack8(reinterpret_cast<const u32x4*>(xb + (int64_t)t * ldx)[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += f[j];
+  }
+  const float inv = 1.0f / (float)T;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] *= inv;
+  reinterpret_cast<u32x4*>(out + (int64_t)blockIdx.y * dim)[i] = pack8(acc);
+}
+}  // namespace
+
+extern "C" int mi355_token_mean(void* out, const void* x, int64_t B, int64_t T, int64_t dim,
+                                int64_t ldx, int64_t x_batch_stride, void* stream) {
+  MI355_REQUIRE(out && x, "token_mean: null pointer");
+  MI355_REQUIRE(B >= 0 && B < 65536 && T > 0 && T < (1ll << 31) && dim > 0 && dim % 8 == 0,
+                "token_mean: bad shape");
+  MI355_REQUIRE(ldx % 8 == 0 && x_batch_stride % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+                    ((uintptr_t)out % 16) == 0,
+                "token_mean: rows must be 16-byte aligned");
+  if (B == 0) return MI355_OK;
+  dim3 grid((unsigned)((dim / 8 + 63) / 64), (unsigned)B), block(64);
+  hipLaunchKernelGGL(token_mean_kernel, grid, block, 0, (hipStream_t)stream,
+                     (const unsigned short*)x, (unsigned short*)out, (int)T, (int)dim, ldx,
+                     x_batch_stride);
+  MI355_CHECK_LAUNCH("token_mean");
   return MI355_OK;
 }
 

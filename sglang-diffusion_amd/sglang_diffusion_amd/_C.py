@@ -111,6 +111,8 @@ SIGNATURES = {
     ),
     "mi355_scale_residual_layernorm_modulate": (
         _int, [_ptr] * 7 + [_i64] * 9 + [_f32, _ptr]),
+    "mi355_layernorm_affine": (_int, [_ptr] * 4 + [_i64] * 4 + [_f32, _ptr]),
+    "mi355_token_mean": (_int, [_ptr, _ptr] + [_i64] * 5 + [_ptr]),
     "mi355_layernorm_modulate_quant": (
         _int,
         [_ptr] * 5 + [_i64] * 5 + [_f32, ctypes.POINTER(RowMap), _ptr],
@@ -470,6 +472,30 @@ def scale_residual_layernorm_modulate(out, res_out, residual, x, gate, shift, sc
             mod.stride(0) if mod is not None else 8, float(eps), _stream(x),
         ),
         "scale_residual_layernorm_modulate",
+    )
+
+
+def layernorm_affine(out, x, weight, bias, eps) -> None:
+    """nn.LayerNorm(dim, eps, elementwise_affine=True) on 2-D [rows, dim] bf16."""
+    rows, dim = x.shape
+    _check(
+        load_library().mi355_layernorm_affine(
+            out.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), rows, dim,
+            x.stride(0), out.stride(0), float(eps), _stream(x),
+        ),
+        "layernorm_affine",
+    )
+
+
+def token_mean(out, x) -> None:
+    """out [B, dim] = mean over dim 1 of x [B, T, dim] (last dim contiguous)."""
+    B, T, dim = x.shape
+    if x.stride(-1) != 1 or not out.is_contiguous():
+        raise RuntimeError("token_mean: last dimension must be contiguous")
+    _check(
+        load_library().mi355_token_mean(out.data_ptr(), x.data_ptr(), B, T, dim, x.stride(1),
+                                        x.stride(0), _stream(x)),
+        "token_mean",
     )
 
 

@@ -25,18 +25,20 @@ run layer by layer.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
 
 from .. import _C
-from ..layers.attention import UlyssesAttention
+from ..layers.attention import LocalAttention, UlyssesAttention
 from ..layers.elementwise import MulAdd
 from ..layers.layernorm import (LayerNormScaleShift, RMSNorm, ScaleResidualLayerNormScaleShift,
                                 _silu)
 from ..layers.linear import ColumnParallelLinear, ReplicatedLinear
 from ..layers.quantization import QuantizationConfig
+from ..layers.rotary import NDRotaryEmbedding
 
 
 def _gelu_tanh(x: torch.Tensor) -> torch.Tensor:
@@ -65,15 +67,17 @@ class ModulateProjection(nn.Module):
 
 
 class MLP(nn.Module):
-    """layers/mlp.py:25-65: fc_out(gelu_tanh(fc_in(x))); both linears take the quant config."""
+    """layers/mlp.py:25-65: fc_out(act(fc_in(x))), act tanh-GELU (DiT blocks) or SiLU (embedders,
+    token refiner); both linears take the quant config."""
 
     def __init__(self, input_dim: int, mlp_hidden_dim: int, output_dim: Optional[int] = None,
                  bias: bool = True, act_type: str = "gelu_pytorch_tanh",
                  dtype: Optional[torch.dtype] = None, prefix: str = "",
                  quant_config: Optional[QuantizationConfig] = None):
         super().__init__()
-        if act_type != "gelu_pytorch_tanh":
-            raise NotImplementedError("MLP: gelu_pytorch_tanh only")
+        if act_type not in ("gelu_pytorch_tanh", "silu"):
+            raise NotImplementedError("MLP: gelu_pytorch_tanh or silu")
+        self.act = _gelu_tanh if act_type == "gelu_pytorch_tanh" else _silu
         dt = dtype or torch.bfloat16
         self.fc_in = ColumnParallelLinear(input_dim, mlp_hidden_dim, bias=True, gather_output=False,
                                           params_dtype=dt, quant_config=quant_config)
@@ -82,7 +86,7 @@ class MLP(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h, _ = self.fc_in(x)
-        y, _ = self.fc_out(_gelu_tanh(h))
+        y, _ = self.fc_out(self.act(h))
         return y
 
 
@@ -215,3 +219,277 @@ def process_weights_after_loading(module: nn.Module) -> None:
         qm = getattr(m, "quant_method", None)
         if qm is not None:
             qm.process_weights_after_loading(m)
+
+
+# ------------------------------------------------------------------- the whole model --
+@dataclass
+class HunyuanVideoArchConfig:
+    """configs/models/dits/hunyuanvideo.py:153-177."""
+
+    patch_size: int = 2
+    patch_size_t: int = 1
+    in_channels: int = 16
+    out_channels: Optional[int] = 16
+    num_attention_heads: int = 24
+    attention_head_dim: int = 128
+    mlp_ratio: float = 4.0
+    num_layers: int = 20
+    num_single_layers: int = 40
+    num_refiner_layers: int = 2
+    rope_axes_dim: Tuple[int, int, int] = (16, 56, 56)
+    guidance_embeds: bool = False
+    text_embed_dim: int = 4096
+    pooled_projection_dim: int = 768
+    rope_theta: int = 256
+
+    @property
+    def hidden_size(self) -> int:
+        return self.attention_head_dim * self.num_attention_heads
+
+
+class _ConvParams(nn.Module):
+    """Holds the weight / bias of the reference's nn.Conv3d under the same state-dict names."""
+
+    def __init__(self, in_chans, embed_dim, patch_size, bias, dtype):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(embed_dim, in_chans, *patch_size, dtype=dtype),
+                                   requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(embed_dim, dtype=dtype), requires_grad=False) \
+            if bias else None
+
+
+class PatchEmbed(nn.Module):
+    """layers/visual_embedding.py:35-86: Conv3d with kernel = stride = patch, flattened to
+    [B, tokens, embed_dim].  A strided convolution over disjoint patches is one GEMM over the
+    unfolded patches ([C, pt, ph, pw] flattened in the weight's own order), fp32 accumulation,
+    bias inside, one rounding -- which is what the convolution computes."""
+
+    def __init__(self, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True,
+                 bias=True, dtype=None, prefix: str = ""):
+        super().__init__()
+        if norm_layer is not None or not flatten:
+            raise NotImplementedError("PatchEmbed: flatten=True without a norm layer only")
+        if not isinstance(patch_size, (list, tuple)) or len(patch_size) != 3:
+            raise NotImplementedError("PatchEmbed: 3-D (t, h, w) patches only")
+        self.patch_size = tuple(patch_size)
+        self.proj = _ConvParams(in_chans, embed_dim, self.patch_size, bias, dtype or torch.bfloat16)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B, C, T, H, W = x.shape
+        pt, ph, pw = self.patch_size
+        t, h, w = T // pt, H // ph, W // pw
+        cols = (x.view(B, C, t, pt, h, ph, w, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+                .reshape(B * t * h * w, C * pt * ph * pw))
+        wmat = self.proj.weight.data.view(self.proj.weight.shape[0], -1)
+        out = torch.empty((cols.shape[0], wmat.shape[0]), dtype=x.dtype, device=x.device)
+        _C.linear_bf16(cols, wmat, None if self.proj.bias is None else self.proj.bias.data, out)
+        return out.view(B, t * h * w, -1)
+
+
+class TimestepEmbedder(nn.Module):
+    """layers/visual_embedding.py:148-220: sinusoidal embedding ([cos | sin], fp32, cast to the
+    weights' dtype) then a SiLU MLP."""
+
+    def __init__(self, hidden_size, act_layer="silu", frequency_embedding_size=256,
+                 max_period=10000, dtype=None, freq_dtype=torch.float32, prefix: str = ""):
+        super().__init__()
+        self.frequency_embedding_size = frequency_embedding_size
+        self.max_period = max_period
+        self.mlp = MLP(frequency_embedding_size, hidden_size, hidden_size, act_type=act_layer,
+                       dtype=dtype)
+
+    def forward(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.reshape(-1).float().contiguous()
+        freq = torch.empty((t.shape[0], self.frequency_embedding_size), dtype=torch.bfloat16,
+                           device=t.device)
+        _C.timestep_embedding(t, freq, True, 0.0, 1.0, float(self.max_period))
+        return self.mlp(freq)
+
+
+class _AffineLayerNorm(nn.Module):
+    """nn.LayerNorm(hidden, eps, elementwise_affine=True) on the HIP kernel."""
+
+    def __init__(self, hidden_size: int, eps: float, dtype):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(hidden_size, dtype=dtype), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(hidden_size, dtype=dtype), requires_grad=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        out = torch.empty_like(x2)
+        _C.layernorm_affine(out, x2, self.weight.data, self.bias.data, self.eps)
+        return out.view(x.shape)
+
+
+class IndividualTokenRefinerBlock(nn.Module):
+    """hunyuanvideo.py:861-957: gated self-attention + SiLU MLP over the text tokens."""
+
+    def __init__(self, hidden_size, num_attention_heads, mlp_ratio=4.0, qkv_bias=True, dtype=None,
+                 prefix: str = ""):
+        super().__init__()
+        dt = dtype or torch.bfloat16
+        self.num_attention_heads = num_attention_heads
+        self.norm1 = _AffineLayerNorm(hidden_size, 1e-6, dt)
+        self.self_attn_qkv = ReplicatedLinear(hidden_size, hidden_size * 3, bias=qkv_bias,
+                                              params_dtype=dt, prefix=f"{prefix}.self_attn_qkv")
+        self.self_attn_proj = ReplicatedLinear(hidden_size, hidden_size, bias=qkv_bias,
+                                               params_dtype=dt, prefix=f"{prefix}.self_attn_proj")
+        self.norm2 = _AffineLayerNorm(hidden_size, 1e-6, dt)
+        self.mlp = MLP(hidden_size, int(hidden_size * mlp_ratio), bias=True, act_type="silu",
+                       dtype=dt, prefix=f"{prefix}.mlp")
+        self.adaLN_modulation = ModulateProjection(hidden_size, factor=2, act_layer="silu", dtype=dt)
+        self.attn = LocalAttention(num_heads=num_attention_heads,
+                                   head_size=hidden_size // num_attention_heads)
+        self.residual = MulAdd()
+
+    def forward(self, x: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+        gate_msa, gate_mlp = self.adaLN_modulation(c).chunk(2, dim=-1)
+        qkv, _ = self.self_attn_qkv(self.norm1(x))
+        B, L = qkv.shape[:2]
+        qkv = qkv.view(B, L, 3, self.num_attention_heads, -1)
+        attn = self.attn(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]).reshape(B, L, -1)
+        attn_out, _ = self.self_attn_proj(attn)
+        x = self.residual(attn_out, gate_msa, x)            # x + attn_out * gate_msa[:, None]
+        return self.residual(self.mlp(self.norm2(x)), gate_mlp, x)
+
+
+class SingleTokenRefiner(nn.Module):
+    """hunyuanvideo.py:787-858."""
+
+    def __init__(self, in_channels, hidden_size, num_attention_heads, depth=2, qkv_bias=True,
+                 dtype=None, prefix: str = ""):
+        super().__init__()
+        dt = dtype or torch.bfloat16
+        self.input_embedder = ReplicatedLinear(in_channels, hidden_size, bias=True, params_dtype=dt,
+                                               prefix=f"{prefix}.input_embedder")
+        self.t_embedder = TimestepEmbedder(hidden_size, act_layer="silu", dtype=dt)
+        self.c_embedder = MLP(in_channels, hidden_size, hidden_size, act_type="silu", dtype=dt)
+        self.refiner_blocks = nn.ModuleList([
+            IndividualTokenRefinerBlock(hidden_size, num_attention_heads, qkv_bias=qkv_bias,
+                                        dtype=dt, prefix=f"{prefix}.refiner_blocks.{i}")
+            for i in range(depth)])
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        mean = torch.empty((x.shape[0], x.shape[2]), dtype=x.dtype, device=x.device)
+        _C.token_mean(mean, x if x.stride(-1) == 1 else x.contiguous())
+        c = self.t_embedder(t) + self.c_embedder(mean)
+        x, _ = self.input_embedder(x)
+        for block in self.refiner_blocks:
+            x = block(x, c)
+        return x
+
+
+class FinalLayer(nn.Module):
+    """hunyuanvideo.py:960-1002: LayerNorm (no affine), * (1 + scale) + shift with the
+    modulation chunked as (scale, shift), then the projection to patch pixels."""
+
+    def __init__(self, hidden_size, patch_size, out_channels, dtype=None, prefix: str = ""):
+        super().__init__()
+        dt = dtype or torch.bfloat16
+        self.norm_final = LayerNormScaleShift(hidden_size, eps=1e-6, dtype=dt)
+        self.linear = ReplicatedLinear(hidden_size,
+                                       patch_size[0] * patch_size[1] * patch_size[2] * out_channels,
+                                       bias=True, params_dtype=dt, prefix=f"{prefix}.linear")
+        self.adaLN_modulation = ModulateProjection(hidden_size, factor=2, act_layer="silu", dtype=dt)
+
+    def forward(self, x: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+        scale, shift = self.adaLN_modulation(c).chunk(2, dim=-1)
+        y, _ = self.linear(self.norm_final(x, shift, scale))
+        return y
+
+
+def unpatchify(x: torch.Tensor, t: int, h: int, w: int, patch_size, channels: int) -> torch.Tensor:
+    """layers/visual_embedding.py:252-274: [B, t*h*w, C*pt*ph*pw] -> [B, C, t*pt, h*ph, w*pw]."""
+    pt, ph, pw = patch_size
+    x = x.reshape(x.shape[0], t, h, w, channels, pt, ph, pw)
+    return x.permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(x.shape[0], channels, t * pt, h * ph, w * pw)
+
+
+def get_rotary_pos_embed(rope_sizes, rope_dim_list, rope_theta, device, sp_rank: int = 0,
+                         sp_world_size: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """layers/rotary_embedding/factory.py:85-171 + mrope.py:296-392: the (t, h, w) grid, the
+    LOCAL frames of this sequence-parallel rank (the grid is sharded along t), flattened with w
+    fastest; per-axis fp32 frequencies.  Returns cos, sin [t_local*h*w, head_dim/2] fp32."""
+    t, h, w = rope_sizes
+    if t % sp_world_size:
+        raise ValueError(f"{t} frames are not divisible by the sequence-parallel size {sp_world_size}")
+    tl = t // sp_world_size
+    grid = torch.stack(torch.meshgrid(
+        torch.arange(sp_rank * tl, (sp_rank + 1) * tl, dtype=torch.float32),
+        torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32),
+        indexing="ij"), dim=-1).reshape(-1, 3)
+    rope = NDRotaryEmbedding(list(rope_dim_list), float(rope_theta), dtype=torch.float32)
+    cos, sin = rope.forward_uncached(grid)
+    return cos.to(device), sin.to(device)
+
+
+class HunyuanVideoTransformer3DModel(nn.Module):
+    """hunyuanvideo.py:413-677 without the cache / offload mix-ins: patch embedding, text token
+    refiner, time / pooled-text / guidance modulation vector, the double and single stream
+    blocks, final layer, unpatchify.  `sp_group`: sequence-parallel (Ulysses) group over which
+    the caller has sharded the FRAMES of hidden_states; None = one rank."""
+
+    def __init__(self, config: HunyuanVideoArchConfig,
+                 quant_config: Optional[QuantizationConfig] = None, sp_group=None,
+                 dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        c = self.config = config
+        self.patch_size = [c.patch_size_t, c.patch_size, c.patch_size]
+        self.out_channels = c.in_channels if c.out_channels is None else c.out_channels
+        self.hidden_size, self.num_attention_heads = c.hidden_size, c.num_attention_heads
+        if sum(c.rope_axes_dim) != c.attention_head_dim:
+            raise ValueError(f"Got {c.rope_axes_dim} but expected positional dim "
+                             f"{c.attention_head_dim}")
+        self.text_states_dim_2 = c.pooled_projection_dim
+        self.sp_group = sp_group
+        H = c.hidden_size
+        self.img_in = PatchEmbed(self.patch_size, c.in_channels, H, dtype=dtype)
+        self.txt_in = SingleTokenRefiner(c.text_embed_dim, H, c.num_attention_heads,
+                                         depth=c.num_refiner_layers, dtype=dtype, prefix="txt_in")
+        self.time_in = TimestepEmbedder(H, act_layer="silu", dtype=dtype)
+        self.vector_in = MLP(c.pooled_projection_dim, H, H, act_type="silu", dtype=dtype)
+        self.guidance_in = TimestepEmbedder(H, act_layer="silu", dtype=dtype) \
+            if c.guidance_embeds else None
+        self.double_blocks = nn.ModuleList([
+            MMDoubleStreamBlock(H, c.num_attention_heads, mlp_ratio=c.mlp_ratio, dtype=dtype,
+                                prefix=f"double_blocks.{i}", quant_config=quant_config,
+                                sp_group=sp_group) for i in range(c.num_layers)])
+        self.single_blocks = nn.ModuleList([
+            MMSingleStreamBlock(H, c.num_attention_heads, mlp_ratio=c.mlp_ratio, dtype=dtype,
+                                prefix=f"single_blocks.{i + c.num_layers}",
+                                quant_config=quant_config, sp_group=sp_group)
+            for i in range(c.num_single_layers)])
+        self.final_layer = FinalLayer(H, self.patch_size, self.out_channels, dtype=dtype)
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                timestep: torch.Tensor, guidance: Optional[torch.Tensor] = None) -> torch.Tensor:
+        import torch.distributed as dist
+
+        x = hidden_states
+        if guidance is None:
+            guidance = torch.tensor([6016.0], device=x.device, dtype=x.dtype)
+        # first text token = pooled (global) embedding, the rest per-token (hunyuanvideo.py:594-600)
+        txt = encoder_hidden_states[:, 1:]
+        text_states_2 = encoder_hidden_states[:, 0, : self.text_states_dim_2]
+        _, _, ot, oh, ow = x.shape
+        tt, th, tw = ot // self.patch_size[0], oh // self.patch_size[1], ow // self.patch_size[2]
+        sp_rank = dist.get_rank(self.sp_group) if self.sp_group is not None else 0
+        sp_size = dist.get_world_size(self.sp_group) if self.sp_group is not None else 1
+        freqs_cis = get_rotary_pos_embed((tt * sp_size, th, tw), self.config.rope_axes_dim,
+                                         self.config.rope_theta, x.device, sp_rank, sp_size)
+        vec = self.time_in(timestep)
+        vec = vec + self.vector_in(text_states_2.contiguous())
+        if self.guidance_in is not None:
+            vec = vec + self.guidance_in(guidance)
+        img = self.img_in(x)
+        txt = self.txt_in(txt, timestep)
+        txt_len, img_len = txt.shape[1], img.shape[1]
+        for block in self.double_blocks:
+            img, txt = block(img, txt, vec, freqs_cis)
+        x = torch.cat((img, txt), 1)
+        for block in self.single_blocks:
+            x = block(x, vec, txt_len, freqs_cis)
+        img = self.final_layer(x[:, :img_len], vec)
+        return unpatchify(img, tt, th, tw, self.patch_size, self.out_channels)

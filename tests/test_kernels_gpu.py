@@ -673,3 +673,25 @@ def test_cfg_normalize_and_guidance_rescale_vs_oracle(device, B, T, C):
         one = noise[:1].to(device).clone()
         _C.guidance_rescale(one, cond[:1].to(device), 0.7)
         assert torch.equal(full[:1], one)
+
+
+@pytest.mark.parametrize("rows,dim", [(5, 256), (77, 3072), (3, 8)])
+def test_layernorm_affine_vs_eager(device, rows, dim):
+    """nn.LayerNorm with affine parameters (text token refiner): fp32 statistics, one rounding."""
+    x = (torch.randn(rows, dim, generator=g(301)) * 2 + 0.3).bfloat16()
+    w = (torch.randn(dim, generator=g(302)) * 0.2 + 1.0).bfloat16()
+    b = (torch.randn(dim, generator=g(303)) * 0.1).bfloat16()
+    ref = torch.nn.functional.layer_norm(x, (dim,), w, b, 1e-6)
+    out = torch.empty(rows, dim, dtype=torch.bfloat16, device=device)
+    _C.layernorm_affine(out, x.to(device), w.to(device), b.to(device), 1e-6)
+    assert_close_bf16(out, ref, rel=1e-3, max_ulps=1.0, what="layernorm_affine")
+    assert mismatch_frac(out, ref) < 0.01
+
+
+def test_token_mean_vs_eager(device):
+    x = torch.randn(3, 21, 192, generator=g(304)).bfloat16()
+    view = x[:, 1:]                                   # the reference averages enc[:, 1:]
+    out = torch.empty(3, 192, dtype=torch.bfloat16, device=device)
+    _C.token_mean(out, x.to(device)[:, 1:])
+    ref = torch.mean(view, dim=1)
+    assert_close_bf16(out, ref, rel=1e-3, max_ulps=1.0, what="token_mean")
