@@ -473,49 +473,67 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
 // out[m][n] = act( sum_k x[m][k] w[n][k] + bias[n] ).  One wavefront per output
 // channel pair; lanes split K in 16-byte chunks, fp32 accumulate, shuffle reduce.
 // Weights are read exactly once from HBM; x (a few KB) stays in L1/L2.
-template <int MMAX>
+template <int MMAX, int SKINNY_CH>
 __global__ __launch_bounds__(256) void skinny_linear_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
     const unsigned short* __restrict__ bias, unsigned short* __restrict__ out, int M, int N, int K,
     int64_t ldx, int64_t ldw, int64_t ldo, int act) {
+  // A wave owns SKINNY_CH consecutive channels: every activation vector it fetches (from
+  // cache) is used against SKINNY_CH weight vectors (from HBM), so the cached re-reads of x
+  // stay below the weight stream instead of being MMAX times it.  Each (m, n) sum keeps the
+  // order it had with one channel per wave: lane-strided over K, then the shuffle tree.
+  constexpr int CH = SKINNY_CH;
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  const u32x4* wr = reinterpret_cast<const u32x4*>(w + (int64_t)n * ldw);
-  float acc[MMAX];
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CH;
+  if (n0 >= N) return;
+  const u32x4* wr[CH];
 #pragma unroll
-  for (int m = 0; m < MMAX; ++m) acc[m] = 0.f;
+  for (int c = 0; c < CH; ++c)
+    wr[c] = reinterpret_cast<const u32x4*>(w + (int64_t)min(n0 + c, N - 1) * ldw);
+  float acc[CH][MMAX];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int m = 0; m < MMAX; ++m) acc[c][m] = 0.f;
   const int nvec = K >> 3;
   for (int idx = lane; idx < nvec; idx += 64) {
-    const u32x4 wv = wr[idx];
-    float wf[8];
+    u32x4 wv[CH];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      wf[2 * j] = __uint_as_float(wv[j] << 16);
-      wf[2 * j + 1] = __uint_as_float(wv[j] & 0xffff0000u);
-    }
+    for (int c = 0; c < CH; ++c) wv[c] = wr[c][idx];
 #pragma unroll
     for (int m = 0; m < MMAX; ++m) {
       if (m < M) {
         const u32x4 xv = *reinterpret_cast<const u32x4*>(x + (int64_t)m * ldx + (int64_t)idx * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[m] = fmaf(__uint_as_float(xv[j] << 16), wf[2 * j], acc[m]);
-          acc[m] = fmaf(__uint_as_float(xv[j] & 0xffff0000u), wf[2 * j + 1], acc[m]);
-        }
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[c][m] = fmaf(__uint_as_float(xv[j] << 16), __uint_as_float(wv[c][j] << 16),
+                             acc[c][m]);
+            acc[c][m] = fmaf(__uint_as_float(xv[j] & 0xffff0000u),
+                             __uint_as_float(wv[c][j] & 0xffff0000u), acc[c][m]);
+          }
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < MMAX; ++m) acc[m] = group_sum<64>(acc[m]);
-  if (lane == 0) {
-    const float b = bias ? bf2f(bias[n]) : 0.f;
+  for (int c = 0; c < CH; ++c)
 #pragma unroll
-    for (int m = 0; m < MMAX; ++m) {
-      if (m < M) {
-        float v = acc[m] + b;
-        if (act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
-        out[(int64_t)m * ldo + n] = f2bf(v);
+    for (int m = 0; m < MMAX; ++m) acc[c][m] = group_sum<64>(acc[c][m]);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int n = n0 + c;
+      if (n < N) {
+        const float b = bias ? bf2f(bias[n]) : 0.f;
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m) {
+          if (m < M) {
+            float v = acc[c][m] + b;
+            if (act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
+            out[(int64_t)m * ldo + n] = f2bf(v);
+          }
+        }
       }
     }
   }
@@ -599,12 +617,22 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
                   "linear_bf16: K and strides must be multiples of 8");
     MI355_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0,
                   "linear_bf16: operands must be 16-byte aligned");
-    dim3 grid((unsigned)((a->N + 3) / 4)), block(256);
+    // four channels per wave once there are enough channels to fill the chip that way
+    const int ch = a->N >= 16384 ? 4 : 1;
+    dim3 grid((unsigned)((a->N + 4 * ch - 1) / (4 * ch))), block(256);
 #define SK(MM)                                                                                     \
-  hipLaunchKernelGGL(skinny_linear_kernel<MM>, grid, block, 0, st, (const unsigned short*)a->a,    \
-                     (const unsigned short*)a->w, (const unsigned short*)a->bias,                  \
-                     (unsigned short*)a->out, (int)a->M, (int)a->N, (int)a->K, a->lda, a->ldw,     \
-                     a->ldo, a->act)
+  do {                                                                                             \
+    if (ch == 4)                                                                                   \
+      hipLaunchKernelGGL((skinny_linear_kernel<MM, 4>), grid, block, 0, st,                        \
+                         (const unsigned short*)a->a, (const unsigned short*)a->w,                 \
+                         (const unsigned short*)a->bias, (unsigned short*)a->out, (int)a->M,       \
+                         (int)a->N, (int)a->K, a->lda, a->ldw, a->ldo, a->act);                    \
+    else                                                                                           \
+      hipLaunchKernelGGL((skinny_linear_kernel<MM, 1>), grid, block, 0, st,                        \
+                         (const unsigned short*)a->a, (const unsigned short*)a->w,                 \
+                         (const unsigned short*)a->bias, (unsigned short*)a->out, (int)a->M,       \
+                         (int)a->N, (int)a->K, a->lda, a->ldw, a->ldo, a->act);                    \
+  } while (0)
     if (a->M <= 1) SK(1);
     else if (a->M <= 2) SK(2);
     else if (a->M <= 4) SK(4);

@@ -157,7 +157,9 @@ def test_fp8_blockwise_scaled_mm_vs_oracle(device, M, N, K):
 
 @pytest.mark.parametrize("M,N,K,act", [(4, 9216, 3072, 0), (1, 64, 256, 0), (16, 3072, 768, 1),
                                         (100, 3072, 64, 0), (257, 264, 192, 1),
-                                        (1024, 12288, 3072, 1), (700, 64, 3072, 0)])
+                                        (1024, 12288, 3072, 1), (700, 64, 3072, 0),
+                                        # small M, many channels: four channels per wave, ragged tail
+                                        (3, 16392 + 8, 256, 0), (16, 18432, 512, 1)])
 def test_linear_bf16_vs_oracle(device, M, N, K, act):
     x = torch.randn(M, K, generator=g(21)).bfloat16()
     w = (torch.randn(N, K, generator=g(22)) * K ** -0.5).bfloat16()
