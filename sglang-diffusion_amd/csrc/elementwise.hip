@@ -134,19 +134,22 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
   constexpr int D = 8 * LPR;
   constexpr int RPB = 256 / LPR;  // rows per block
   const int sub = threadIdx.x % LPR;
-  const int64_t rows_one = B * S * H;
-  const int64_t gr = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  // 32-bit row arithmetic (the entry point checks 2*B*S*H < 2^31): 64-bit divisions would cost
+  // more instructions than the rest of the thread's work
+  const unsigned rows_one = (unsigned)(B * S * H);
+  const unsigned gr = blockIdx.x * (unsigned)RPB + threadIdx.x / LPR;
   // q == nullptr: only the key rows are processed (the query side is done by the attention
   // kernel as it loads Q)
-  const int64_t rows_all = q ? 2 * rows_one : rows_one;
+  const unsigned rows_all = q ? 2 * rows_one : rows_one;
   const bool live = gr < rows_all;
-  const int64_t g = live ? gr : rows_all - 1;
+  const unsigned g = live ? gr : rows_all - 1;
   const bool is_k = q ? g >= rows_one : true;
-  const int64_t rrow = (q && is_k) ? g - rows_one : g;
-  const int64_t hh = rrow % H;
-  const int64_t tok = rrow / H;
-  const int64_t s = tok % S;
-  const int64_t b = tok / S;
+  const unsigned rrow = (q && is_k) ? g - rows_one : g;
+  const unsigned tok = rrow / (unsigned)H;
+  const int64_t hh = rrow - tok * (unsigned)H;
+  const unsigned bu = tok / (unsigned)S;
+  const int64_t s = tok - bu * (unsigned)S;
+  const int64_t b = bu;
   unsigned short* base = (is_k ? k : q) + b * sb + s * ss + hh * sh;
   u32x4* p = reinterpret_cast<u32x4*>(base) + sub;
   float f[8];
@@ -580,6 +583,7 @@ extern "C" int mi355_qk_norm_rope(void* q, void* k, int64_t B, int64_t S, int64_
     MI355_REQUIRE(((uintptr_t)cos % 16) == 0 && ((uintptr_t)sin % 16) == 0,
                   "qk_norm_rope: cos/sin must be 16-byte aligned");
   const int64_t rows = (q ? 2 : 1) * B * S * H;
+  MI355_REQUIRE(rows < (1ll << 31), "qk_norm_rope: too many (token, head) rows");
   if (rows == 0) return MI355_OK;
   hipStream_t st = (hipStream_t)stream;
   if (D == 128) {
