@@ -23,6 +23,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -425,19 +427,21 @@ template <int D, bool TRREAD, bool F16>
 int launch_attn(const AttnParams& p, hipStream_t st) {
   constexpr int LDS = 2 * 2 * 64 * D * 2;
   // the LDS limit is a per-device function attribute: remember which devices have it
-  static unsigned long long attr_devices = 0;
+  // callers may launch from several host threads: the per-device flags are atomic (a lost
+  // update would only repeat the attribute call)
+  static std::atomic<unsigned long long> attr_devices{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
   auto kfn = attn_fwd_kernel<D, TRREAD, F16>;
-  if (!(attr_devices & dev_bit)) {
+  if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mi355_set_error("flash_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MI355_EHIP;
     }
-    attr_devices |= dev_bit;
+    attr_devices.fetch_or(dev_bit, std::memory_order_release);
   }
   dim3 grid((unsigned)((p.Sq + 127) / 128), (unsigned)p.H, (unsigned)p.B), block(256);
   hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
@@ -455,7 +459,7 @@ static int attn_entry(const void* q, const void* k, const void* v, void* out, fl
                       void* stream, const float* qw0 = nullptr, const float* qw1 = nullptr,
                       int64_t q_split = 0, float q_eps = 0.f, const float* qcos = nullptr,
                       const float* qsin = nullptr) {
-  MI355_REQUIRE(q && k && v && out, "flash_attn_fwd: null pointer");
+  MI355_REQUIRE(B == 0 || Sq == 0 || (q && k && v && out), "flash_attn_fwd: null pointer");
   if (causal) {
     mi355_set_error("flash_attn_fwd: causal masking is not built (the DiT path is non-causal)");
     return MI355_ENOSUP;

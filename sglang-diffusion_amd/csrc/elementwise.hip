@@ -512,7 +512,7 @@ inline unsigned grid_for(int64_t work_items, int per_block = 256, int64_t cap = 
 
 extern "C" int mi355_rmsnorm(void* out, const void* x, const void* w, int w_is_f32, int64_t rows,
                              int64_t dim, int64_t ldx, int64_t ldo, float eps, void* stream) {
-  MI355_REQUIRE(out && x && w, "rmsnorm: null pointer");
+  MI355_REQUIRE(rows == 0 || (out && x && w), "rmsnorm: null pointer");
   MI355_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0,
                 "rmsnorm: dim (%ld) and strides must be multiples of 8", (long)dim);
   MI355_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)w % 16) == 0,
@@ -532,7 +532,7 @@ extern "C" int mi355_rmsnorm(void* out, const void* x, const void* w, int w_is_f
 
 extern "C" int mi355_fused_add_rmsnorm(void* x, void* residual, const void* w, int w_is_f32,
                                        int64_t rows, int64_t dim, float eps, void* stream) {
-  MI355_REQUIRE(x && residual && w, "fused_add_rmsnorm: null pointer");
+  MI355_REQUIRE(rows == 0 || (x && residual && w), "fused_add_rmsnorm: null pointer");
   MI355_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0, "fused_add_rmsnorm: dim %% 8 != 0");
   MI355_REQUIRE(dim <= 16384, "fused_add_rmsnorm: dim (%ld) > 16384 not built", (long)dim);
   MI355_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
@@ -569,7 +569,7 @@ extern "C" int mi355_qk_norm_rope(void* q, void* k, int64_t B, int64_t S, int64_
                                   const float* wk0, const float* wq1, const float* wk1,
                                   int64_t s_split, float eps, const float* cos, const float* sin,
                                   int interleaved, void* stream) {
-  MI355_REQUIRE(k, "qk_norm_rope: null key pointer");
+  MI355_REQUIRE(B * S * H == 0 || k, "qk_norm_rope: null key pointer");
   MI355_REQUIRE(D == 128 || D == 64, "qk_norm_rope: head size %ld not in {64,128}", (long)D);
   MI355_REQUIRE(B >= 0 && S >= 0 && H > 0, "qk_norm_rope: bad shape");
   MI355_REQUIRE(sb % 8 == 0 && ss % 8 == 0 && sh % 8 == 0 && ((uintptr_t)q % 16) == 0 &&
@@ -606,8 +606,8 @@ extern "C" int mi355_rotary_embedding(const int64_t* positions, void* q, void* k
                                       int64_t q_stride, int64_t k_stride,
                                       const void* cos_sin_cache, int cache_is_f32, int is_neox,
                                       void* stream) {
-  MI355_REQUIRE(positions && q && cos_sin_cache, "rotary_embedding: null pointer");
-  MI355_REQUIRE(k != nullptr || Hk == 0, "rotary_embedding: key missing but Hk > 0");
+  MI355_REQUIRE(tokens == 0 || (positions && q && cos_sin_cache), "rotary_embedding: null pointer");
+  MI355_REQUIRE(tokens == 0 || k != nullptr || Hk == 0, "rotary_embedding: key missing but Hk > 0");
   MI355_REQUIRE(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size,
                 "rotary_embedding: rot_dim %ld invalid for head_size %ld", (long)rot_dim,
                 (long)head_size);
@@ -631,7 +631,7 @@ static int launch_ln_mod(void* out, float* qscale, const void* x, const void* sh
                          const void* scale, int64_t B, int64_t T, int64_t dim, int64_t ldx,
                          int64_t ldo, int64_t ldmod, float eps, const mi355_rowmap* x_map,
                          const mi355_rowmap* o_map, int quant, void* stream) {
-  MI355_REQUIRE(out && x, "layernorm_modulate: null pointer");
+  MI355_REQUIRE(B * T == 0 || (out && x), "layernorm_modulate: null pointer");
   MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0 && dim <= 16384,
                 "layernorm_modulate: dim (%ld) must be a multiple of 8 and <= 16384", (long)dim);
   MI355_REQUIRE(B * T < (1ll << 31), "layernorm_modulate: too many rows");
@@ -685,7 +685,7 @@ extern "C" int mi355_layernorm_modulate_quant(void* q, float* s, const void* x, 
                                               const void* scale, int64_t B, int64_t T, int64_t dim,
                                               int64_t ldx, int64_t ldmod, float eps,
                                               const mi355_rowmap* x_map, void* stream) {
-  MI355_REQUIRE(s != nullptr, "layernorm_modulate_quant: null scale output");
+  MI355_REQUIRE(B * T == 0 || s != nullptr, "layernorm_modulate_quant: null scale output");
   return launch_ln_mod(q, s, x, shift, scale, B, T, dim, ldx, /*ldo*/ 8, ldmod, eps, x_map,
                        nullptr, 1, stream);
 }
@@ -695,7 +695,7 @@ extern "C" int mi355_layernorm_modulate_group_quant(void* q, float* s, const voi
                                                     int64_t B, int64_t T, int64_t dim, int64_t ldx,
                                                     int64_t ldmod, float eps,
                                                     const mi355_rowmap* x_map, void* stream) {
-  MI355_REQUIRE(s != nullptr, "layernorm_modulate_group_quant: null scale output");
+  MI355_REQUIRE(B * T == 0 || s != nullptr, "layernorm_modulate_group_quant: null scale output");
   MI355_REQUIRE(dim % 128 == 0, "layernorm_modulate_group_quant: dim (%ld) must be a multiple of 128",
                 (long)dim);
   return launch_ln_mod(q, s, x, shift, scale, B, T, dim, ldx, /*ldo*/ 8, ldmod, eps, x_map,
@@ -706,7 +706,8 @@ extern "C" int mi355_scale_residual_layernorm_modulate(
     void* out, void* res_out, const void* residual, const void* x, const void* gate,
     const void* shift, const void* scale, int64_t B, int64_t T, int64_t dim, int64_t ldx,
     int64_t ldr, int64_t ldo, int64_t ldro, int64_t ldg, int64_t ldmod, float eps, void* stream) {
-  MI355_REQUIRE(out && res_out && residual && x, "scale_residual_layernorm_modulate: null pointer");
+  MI355_REQUIRE(B * T == 0 || (out && res_out && residual && x),
+                "scale_residual_layernorm_modulate: null pointer");
   MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0 && dim <= 16384,
                 "scale_residual_layernorm_modulate: dim (%ld) must be a multiple of 8 and <= 16384",
                 (long)dim);
@@ -745,7 +746,7 @@ extern "C" int mi355_scale_residual_layernorm_modulate(
 extern "C" int mi355_layernorm_affine(void* out, const void* x, const void* weight,
                                       const void* bias, int64_t rows, int64_t dim, int64_t ldx,
                                       int64_t ldo, float eps, void* stream) {
-  MI355_REQUIRE(out && x && weight && bias, "layernorm_affine: null pointer");
+  MI355_REQUIRE(rows == 0 || (out && x && weight && bias), "layernorm_affine: null pointer");
   MI355_REQUIRE(rows >= 0 && rows < (1ll << 31) && dim > 0 && dim % 8 == 0 && dim <= 16384,
                 "layernorm_affine: dim (%ld) must be a multiple of 8 and <= 16384", (long)dim);
   MI355_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(64) void token_mean_kernel(const unsigned short* __
 
 extern "C" int mi355_token_mean(void* out, const void* x, int64_t B, int64_t T, int64_t dim,
                                 int64_t ldx, int64_t x_batch_stride, void* stream) {
-  MI355_REQUIRE(out && x, "token_mean: null pointer");
+  MI355_REQUIRE(B == 0 || (out && x), "token_mean: null pointer");
   MI355_REQUIRE(B >= 0 && B < 65536 && T > 0 && T < (1ll << 31) && dim > 0 && dim % 8 == 0,
                 "token_mean: bad shape");
   MI355_REQUIRE(ldx % 8 == 0 && x_batch_stride % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
@@ -821,7 +822,7 @@ extern "C" int mi355_gate_residual(void* out, const void* residual, const void* 
                                    int64_t ldr, int64_t ldo, int64_t ldg,
                                    const mi355_rowmap* y_map, const mi355_rowmap* r_map,
                                    void* stream) {
-  MI355_REQUIRE(out && residual && gate && y, "gate_residual: null pointer");
+  MI355_REQUIRE(B == 0 || (out && residual && gate && y), "gate_residual: null pointer");
   MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0, "gate_residual: dim %% 8 != 0");
   MI355_REQUIRE(B * T < (1ll << 31), "gate_residual: too many rows");
   MI355_REQUIRE(ldy % 8 == 0 && ldr % 8 == 0 && ldo % 8 == 0 && ldg % 8 == 0 &&
@@ -842,7 +843,7 @@ extern "C" int mi355_gate_residual(void* out, const void* residual, const void* 
 
 extern "C" int mi355_activation(void* out, const void* x, int64_t rows, int64_t dim, int64_t ldx,
                                 int64_t ldo, int act, void* stream) {
-  MI355_REQUIRE(out && x, "activation: null pointer");
+  MI355_REQUIRE(rows == 0 || (out && x), "activation: null pointer");
   MI355_REQUIRE(act == 0 || act == 1, "activation: unknown act %d", act);
   MI355_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 &&
                     ((uintptr_t)out % 16) == 0 && ((uintptr_t)x % 16) == 0,
@@ -859,7 +860,7 @@ extern "C" int mi355_timestep_embedding(const float* t, void* out, int64_t B, in
                                         int flip_sin_to_cos, float downscale_freq_shift,
                                         float scale, float max_period, int out_bf16,
                                         void* stream) {
-  MI355_REQUIRE(t && out, "timestep_embedding: null pointer");
+  MI355_REQUIRE(B == 0 || (t && out), "timestep_embedding: null pointer");
   MI355_REQUIRE(B >= 0 && dim >= 2, "timestep_embedding: bad shape");
   if (B == 0) return MI355_OK;
   const int64_t total = B * (dim / 2);
@@ -886,7 +887,7 @@ static float host_round_bf16(float f) {
 
 extern "C" int mi355_euler_step(void* out, const void* sample, const void* v, float sigma,
                                 float sigma_next, int64_t n, void* stream) {
-  MI355_REQUIRE(out && sample && v, "euler_step: null pointer");
+  MI355_REQUIRE(n == 0 || (out && sample && v), "euler_step: null pointer");
   MI355_REQUIRE(n >= 0, "euler_step: negative size");
   MI355_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)sample % 16) == 0 &&
                     ((uintptr_t)v % 16) == 0,
@@ -902,7 +903,7 @@ extern "C" int mi355_euler_step(void* out, const void* sample, const void* v, fl
 
 extern "C" int mi355_cfg_combine(void* out, const void* cond, const void* uncond, float scale,
                                  int64_t n, void* stream) {
-  MI355_REQUIRE(out && cond && uncond, "cfg_combine: null pointer");
+  MI355_REQUIRE(n == 0 || (out && cond && uncond), "cfg_combine: null pointer");
   MI355_REQUIRE(n >= 0, "cfg_combine: negative size");
   MI355_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)cond % 16) == 0 &&
                     ((uintptr_t)uncond % 16) == 0,
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(256) void guidance_rescale_apply_kernel(
 
 extern "C" int mi355_cfg_normalize(void* noise, const void* cond, float factor, int64_t n,
                                    float* scratch, void* stream) {
-  MI355_REQUIRE(noise && cond && scratch, "cfg_normalize: null pointer");
+  MI355_REQUIRE(n == 0 || (noise && cond && scratch), "cfg_normalize: null pointer");
   MI355_REQUIRE(n >= 0 && n % 8 == 0, "cfg_normalize: n must be a multiple of 8");
   MI355_REQUIRE(((uintptr_t)noise % 16) == 0 && ((uintptr_t)cond % 16) == 0 &&
                     ((uintptr_t)scratch % 16) == 0,
@@ -1042,7 +1043,8 @@ extern "C" int mi355_cfg_normalize(void* noise, const void* cond, float factor, 
 extern "C" int mi355_guidance_rescale(void* noise, const void* cond, float guidance_rescale,
                                       int64_t batch, int64_t per_sample, float* scratch,
                                       void* stream) {
-  MI355_REQUIRE(noise && cond && scratch, "guidance_rescale: null pointer");
+  MI355_REQUIRE(batch == 0 || (noise && cond && scratch), "guidance_rescale: null pointer");
+  if (batch == 0 || !(guidance_rescale > 0.f)) return MI355_OK;
   MI355_REQUIRE(batch >= 0 && batch < 65536 && per_sample >= 8 && per_sample % 8 == 0,
                 "guidance_rescale: batch < 65536 and per_sample a multiple of 8");
   MI355_REQUIRE(((uintptr_t)noise % 16) == 0 && ((uintptr_t)cond % 16) == 0 &&

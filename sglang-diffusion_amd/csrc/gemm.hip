@@ -19,6 +19,8 @@
 // 32x32 accumulator has the token (m) on the lane and 4-element runs of n in
 // registers: after one permlane32_swap per register pair every lane owns 8
 // consecutive output channels of one token and stores 16 bytes.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -541,15 +543,17 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(
 
 // workgroups of one kernel that are resident at once: CUs x (workgroups per CU by LDS)
 int resident_workgroups(int lds_bytes) {
-  static int cus_of[64] = {0};
+  static std::atomic<int> cus_of[64];
   int dev = 0;
   (void)hipGetDevice(&dev);
-  int& cus = cus_of[dev & 63];
+  std::atomic<int>& slot = cus_of[dev & 63];
+  int cus = slot.load(std::memory_order_relaxed);
   if (cus == 0) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
     cus = n;
+    slot.store(n, std::memory_order_relaxed);
   }
   const int per_cu = lds_bytes > 80 * 1024 ? 1 : 2;
   return cus * per_cu;
@@ -560,19 +564,21 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int LDS = 2 * (BM + BN) * 128;
   // the LDS limit is a per-device function attribute: remember which devices have it
-  static unsigned long long attr_devices = 0;
+  // callers may launch from several host threads: the per-device flags are atomic (a lost
+  // update would only repeat the attribute call)
+  static std::atomic<unsigned long long> attr_devices{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
   auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS>;
-  if (!(attr_devices & dev_bit)) {
+  if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mi355_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MI355_EHIP;
     }
-    attr_devices |= dev_bit;
+    attr_devices.fetch_or(dev_bit, std::memory_order_release);
   }
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
@@ -583,7 +589,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
 }
 
 int check_common(const mi355_linear_args* a, const char* who) {
-  MI355_REQUIRE(a->a && a->w && a->out, "%s: null pointer", who);
+  MI355_REQUIRE(a->M == 0 || (a->a && a->w && a->out), "%s: null pointer", who);
   MI355_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "%s: bad shape M=%ld N=%ld K=%ld", who,
                 (long)a->M, (long)a->N, (long)a->K);
   MI355_REQUIRE(a->M < (1ll << 31) && a->N < (1ll << 31) && a->K < (1ll << 31),
@@ -743,7 +749,7 @@ extern "C" int mi355_fp8_blockwise_scaled_mm(const void* a, const void* b, const
                                              int64_t K, int64_t lda, int64_t ldb, int64_t ldo,
                                              int64_t sa_sm, int64_t sa_sk, int64_t sb_sk,
                                              int64_t sb_sn, void* stream) {
-  MI355_REQUIRE(a && b && sa && sb && out, "fp8_blockwise_scaled_mm: null pointer");
+  MI355_REQUIRE(M == 0 || (a && b && sa && sb && out), "fp8_blockwise_scaled_mm: null pointer");
   MI355_REQUIRE(M >= 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31),
                 "fp8_blockwise_scaled_mm: bad shape");
   MI355_REQUIRE(K % 128 == 0, "fp8_blockwise_scaled_mm: K (%ld) must be a multiple of 128",

@@ -170,7 +170,7 @@ extern "C" int mi355_per_token_quant_fp8(const void* x, int64_t M, int64_t K, in
                                          void* q, float* s, void* stream) {
   MI355_REQUIRE(M >= 0 && K > 0, "per_token_quant_fp8: bad shape M=%ld K=%ld", (long)M, (long)K);
   if (M == 0) return MI355_OK;  // empty batch: nothing to launch (pointers may be null)
-  MI355_REQUIRE(x && q && s, "per_token_quant_fp8: null pointer");
+  MI355_REQUIRE(M == 0 || (x && q && s), "per_token_quant_fp8: null pointer");
   MI355_REQUIRE(K % 8 == 0 && ldx % 8 == 0,
                 "per_token_quant_fp8: K (%ld) and row stride (%ld) must be multiples of 8",
                 (long)K, (long)ldx);
@@ -260,7 +260,7 @@ extern "C" int mi355_per_token_group_quant_fp8(const void* x, int64_t M, int64_t
                                                int64_t s_stride_g, int group_size, float eps,
                                                float fp8_min, float fp8_max, int scale_ue8m0,
                                                void* stream) {
-  MI355_REQUIRE(x && q && s, "per_token_group_quant_fp8: null pointer");
+  MI355_REQUIRE(M == 0 || (x && q && s), "per_token_group_quant_fp8: null pointer");
   if (scale_ue8m0) {
     mi355_set_error("per_token_group_quant_fp8: packed UE8M0 scales are not built");
     return MI355_ENOSUP;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void per_tensor_quant_fp8_kernel(
 
 extern "C" int mi355_per_tensor_quant_fp8(const void* x, int64_t numel, void* q, float* s,
                                           int is_static, void* stream) {
-  MI355_REQUIRE(x && q && s, "per_tensor_quant_fp8: null pointer");
+  MI355_REQUIRE(numel == 0 || (x && q && s), "per_tensor_quant_fp8: null pointer");
   MI355_REQUIRE(numel >= 0, "per_tensor_quant_fp8: negative numel");
   MI355_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 8) == 0,
                 "per_tensor_quant_fp8: misaligned input/output");

@@ -697,3 +697,28 @@ def test_token_mean_vs_eager(device):
     _C.token_mean(out, x.to(device)[:, 1:])
     ref = torch.mean(view, dim=1)
     assert_close_bf16(out, ref, rel=1e-3, max_ulps=1.0, what="token_mean")
+
+
+def test_empty_inputs_are_no_ops(device):
+    """Zero rows / zero tokens / zero elements: every entry point returns without launching
+    (an empty batch reaches the kernels when a scheduler step has nothing for a rank)."""
+    bf = dict(dtype=torch.bfloat16, device=device)
+    e2 = torch.empty(0, 256, **bf)
+    w = torch.zeros(128, 256, **bf)
+    out = torch.empty(0, 128, **bf)
+    _C.linear_bf16(e2, w, None, out)
+    _C.fp8_scaled_mm(torch.empty(0, 256, dtype=FP8, device=device),
+                     torch.zeros(128, 256, dtype=FP8, device=device),
+                     torch.empty(0, device=device), torch.ones(128, device=device), None, out)
+    _C.layernorm_modulate(torch.empty(0, 256, **bf), e2, torch.zeros(1, 256, **bf),
+                          torch.zeros(1, 256, **bf), 0, 7, 1e-6)
+    _C.layernorm_affine(torch.empty(0, 256, **bf), e2, torch.ones(256, **bf), torch.zeros(256, **bf), 1e-6)
+    q = torch.empty(0, 5, 2, 128, **bf)
+    _C.qk_norm_rope(q, q.clone(), None, None, None, None, 0, 1e-6, None, None, True)
+    _C.flash_attn_fwd(q, q, q, torch.empty_like(q), None, 0.1)
+    z = torch.empty(0, **bf)
+    _C.cfg_combine(z, z, z, 3.5)
+    _C.euler_step(z, z, z, 1.0, 0.9)
+    _C.cfg_normalize(torch.empty(0, 8, **bf), torch.empty(0, 8, **bf), 1.0)
+    _C.guidance_rescale(torch.empty(0, 8, **bf), torch.empty(0, 8, **bf), 0.7)
+    torch.cuda.synchronize()
