@@ -49,6 +49,11 @@ if mode == "tail":
         t = (M // 256) * (N // 256)
         print(f"tiles {t} = {t / 256:.3f} rounds", flush=True)
         bench(True, M, N, K)
+if mode == "txt":
+    # the text-stream GEMMs of a double block (M = 4 x 512 rows) and the image-stream ones
+    for (fp8, M, N, K) in [(False, 2048, 3072, 12288), (False, 2048, 12288, 3072), (True, 2048, 9216, 3072),
+                           (True, 2048, 3072, 3072), (False, 16384, 3072, 12288), (True, 18432, 3072, 15360)]:
+        bench(fp8, M, N, K)
 if mode in ("bf16", "both"):
     for (M, N, K) in [(16384, 12288, 3072), (16384, 3072, 12288), (8192, 8192, 8192)]:
         bench(False, M, N, K)
