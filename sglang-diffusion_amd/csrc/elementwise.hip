@@ -254,12 +254,23 @@ struct LnPre {
   int64_t ldr, ldro, ldg;
 };
 
-template <int NCH, int QUANT, bool PRE = false>
+// MOD: 0 = plain LayerNorm; 1 = * (1 + scale) + shift with eager's three roundings (both rows
+// given); 2 = affine nn.LayerNorm (scale row = weight, shift row = bias), one rounding.
+constexpr int LN_PLAIN = 0, LN_MODULATE = 1, LN_AFFINE = 2;
+
+// two eager-mode bf16 rounding points with one v_cvt_pk_bf16_f32
+__device__ __forceinline__ void rbf2(float& a, float& b) {
+  const unsigned int p = pack_bf2(a, b);
+  a = __uint_as_float(p << 16);
+  b = __uint_as_float(p & 0xffff0000u);
+}
+
+template <int NCH, int QUANT, bool PRE = false, int MOD = LN_MODULATE>
 __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     void* __restrict__ out, float* __restrict__ qscale, const unsigned short* __restrict__ x,
     const unsigned short* __restrict__ shift, const unsigned short* __restrict__ scale, int64_t rows,
     int T, int dim, int64_t ldx, int64_t ldo, int64_t ldmod, float eps, mi355_rowmap xm,
-    mi355_rowmap om, LnPre pre = LnPre{}, int affine = 0) {
+    mi355_rowmap om, LnPre pre = LnPre{}) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -310,8 +321,12 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
   }
   sq = group_sum<64>(sq);
   const float rstd = rsqrtf(sq / (float)dim + eps);
-  const u32x4* shr = shift ? reinterpret_cast<const u32x4*>(shift + b * ldmod) : nullptr;
-  const u32x4* scr = scale ? reinterpret_cast<const u32x4*>(scale + b * ldmod) : nullptr;
+  const u32x4* shr = nullptr;
+  const u32x4* scr = nullptr;
+  if constexpr (MOD != LN_PLAIN) {
+    shr = reinterpret_cast<const u32x4*>(shift + b * ldmod);
+    scr = reinterpret_cast<const u32x4*>(scale + b * ldmod);
+  }
   float amax = 0.f;
   float gmax[QUANT == 2 ? NCH : 1];
 #pragma unroll
@@ -320,22 +335,41 @@ __global__ __launch_bounds__(256) void layernorm_modulate_kernel(
     if constexpr (QUANT == 2) gmax[c] = 1e-10f;
     if (i < nvec) {
       float sc[8], sh[8];
-      if (scr) unpack8(scr[i], sc);
-      if (shr) unpack8(shr[i], sh);
+      if constexpr (MOD != LN_PLAIN) {
+        unpack8(scr[i], sc);
+        unpack8(shr[i], sh);
+      }
+      if constexpr (MOD == LN_MODULATE) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float y;
-        if (affine) {
-          // nn.LayerNorm with weight (scale row) and bias (shift row): one rounding at the end
-          y = rbf((v[c][j] - mean) * rstd * sc[j] + sh[j]);
-        } else {
-          y = rbf((v[c][j] - mean) * rstd);        // LayerNorm output (bf16)
-          if (scr) y = rbf(y * rbf(1.0f + sc[j]));  // * (1 + scale)
-          if (shr) y = rbf(y + sh[j]);              // + shift
+        for (int j = 0; j < 8; j += 2) {
+          sc[j] = 1.0f + sc[j];
+          sc[j + 1] = 1.0f + sc[j + 1];
+          rbf2(sc[j], sc[j + 1]);  // (1 + scale) is a bf16 tensor in eager
         }
-        v[c][j] = y;
-        if constexpr (QUANT == 2) gmax[c] = fmaxf(gmax[c], fabsf(y));
-        else amax = fmaxf(amax, fabsf(y));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        float y0 = (v[c][j] - mean) * rstd, y1 = (v[c][j + 1] - mean) * rstd;
+        if constexpr (MOD == LN_AFFINE) {
+          // nn.LayerNorm with weight (scale row) and bias (shift row): one rounding at the end
+          y0 = y0 * sc[j] + sh[j];
+          y1 = y1 * sc[j + 1] + sh[j + 1];
+          rbf2(y0, y1);
+        } else {
+          rbf2(y0, y1);  // LayerNorm output (bf16)
+          if constexpr (MOD == LN_MODULATE) {
+            y0 *= sc[j];
+            y1 *= sc[j + 1];
+            rbf2(y0, y1);  // * (1 + scale)
+            y0 += sh[j];
+            y1 += sh[j + 1];
+            rbf2(y0, y1);  // + shift
+          }
+        }
+        v[c][j] = y0;
+        v[c][j + 1] = y1;
+        if constexpr (QUANT == 2) gmax[c] = fmaxf(gmax[c], fmaxf(fabsf(y0), fabsf(y1)));
+        else if constexpr (QUANT == 1) amax = fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1)));
       }
     }
   }
@@ -632,6 +666,9 @@ static int launch_ln_mod(void* out, float* qscale, const void* x, const void* sh
                          int64_t ldo, int64_t ldmod, float eps, const mi355_rowmap* x_map,
                          const mi355_rowmap* o_map, int quant, void* stream) {
   MI355_REQUIRE(B * T == 0 || (out && x), "layernorm_modulate: null pointer");
+  MI355_REQUIRE((shift == nullptr) == (scale == nullptr),
+                "layernorm_modulate: give both shift and scale, or neither");
+  MI355_REQUIRE(!quant || shift, "layernorm_modulate: the quantising forms need shift and scale");
   MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0 && dim <= 16384,
                 "layernorm_modulate: dim (%ld) must be a multiple of 8 and <= 16384", (long)dim);
   MI355_REQUIRE(B * T < (1ll << 31), "layernorm_modulate: too many rows");
@@ -645,19 +682,21 @@ static int launch_ln_mod(void* out, float* qscale, const void* x, const void* sh
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int nch = (int)((dim / 8 + 63) / 64);
-#define LN(N, Q)                                                                                  \
-  hipLaunchKernelGGL((layernorm_modulate_kernel<N, Q>), grid, block, 0, st, out, qscale,          \
+#define LN(N, Q, M)                                                                               \
+  hipLaunchKernelGGL((layernorm_modulate_kernel<N, Q, false, M>), grid, block, 0, st, out, qscale, \
                      (const unsigned short*)x, (const unsigned short*)shift,                      \
                      (const unsigned short*)scale, rows, (int)T, (int)dim, ldx, ldo, ldmod, eps,  \
                      xm, om)
-#define LNQ(N)          \
-  do {                  \
-    if (quant == 2)     \
-      LN(N, 2);         \
-    else if (quant)     \
-      LN(N, 1);         \
-    else                \
-      LN(N, 0);         \
+#define LNQ(N)                      \
+  do {                              \
+    if (quant == 2)                 \
+      LN(N, 2, LN_MODULATE);        \
+    else if (quant)                 \
+      LN(N, 1, LN_MODULATE);        \
+    else if (shift)                 \
+      LN(N, 0, LN_MODULATE);        \
+    else                            \
+      LN(N, 0, LN_PLAIN);           \
   } while (0)
   if (nch <= 1) LNQ(1);
   else if (nch <= 2) LNQ(2);
@@ -706,7 +745,7 @@ extern "C" int mi355_scale_residual_layernorm_modulate(
     void* out, void* res_out, const void* residual, const void* x, const void* gate,
     const void* shift, const void* scale, int64_t B, int64_t T, int64_t dim, int64_t ldx,
     int64_t ldr, int64_t ldo, int64_t ldro, int64_t ldg, int64_t ldmod, float eps, void* stream) {
-  MI355_REQUIRE(B * T == 0 || (out && res_out && residual && x),
+  MI355_REQUIRE(B * T == 0 || (out && res_out && residual && x && shift && scale),
                 "scale_residual_layernorm_modulate: null pointer");
   MI355_REQUIRE(B >= 0 && T > 0 && dim > 0 && dim % 8 == 0 && dim <= 16384,
                 "scale_residual_layernorm_modulate: dim (%ld) must be a multiple of 8 and <= 16384",
@@ -727,7 +766,7 @@ extern "C" int mi355_scale_residual_layernorm_modulate(
   hipStream_t st = (hipStream_t)stream;
   const int nch = (int)((dim / 8 + 63) / 64);
 #define LNP(N)                                                                                     \
-  hipLaunchKernelGGL((layernorm_modulate_kernel<N, 0, true>), grid, block, 0, st, out,             \
+  hipLaunchKernelGGL((layernorm_modulate_kernel<N, 0, true, LN_MODULATE>), grid, block, 0, st, out, \
                      (float*)nullptr, (const unsigned short*)x, (const unsigned short*)shift,      \
                      (const unsigned short*)scale, rows, (int)T, (int)dim, ldx, ldo, ldmod, eps,   \
                      id, id, pre)
@@ -760,10 +799,10 @@ extern "C" int mi355_layernorm_affine(void* out, const void* x, const void* weig
   const int nch = (int)((dim / 8 + 63) / 64);
   // T = rows: every row reads modulation row 0, which is the weight / bias vector
 #define LNA(N)                                                                                     \
-  hipLaunchKernelGGL((layernorm_modulate_kernel<N, 0, false>), grid, block, 0, st, out,            \
+  hipLaunchKernelGGL((layernorm_modulate_kernel<N, 0, false, LN_AFFINE>), grid, block, 0, st, out, \
                      (float*)nullptr, (const unsigned short*)x, (const unsigned short*)bias,       \
                      (const unsigned short*)weight, rows, (int)rows, (int)dim, ldx, ldo,           \
-                     (int64_t)0, eps, id, id, LnPre{}, 1)
+                     (int64_t)0, eps, id, id, LnPre{})
   if (nch <= 1) LNA(1);
   else if (nch <= 2) LNA(2);
   else if (nch <= 4) LNA(4);
