@@ -198,3 +198,37 @@ def test_dp_batch_scheduler_on_the_hip_path(device):
     assert len(outs) == len(specs)
     for got, exp in zip(outs, alone):
         assert torch.equal(got, exp)
+
+
+def test_fused_step_replays_from_a_hip_graph(device):
+    """A serving loop can capture the fused DiT forward once and replay it: every launch goes
+    to the capturing stream, nothing synchronises, and the workspace is allocated before the
+    capture.  The replay on NEW input values equals the eager call bit for bit."""
+    model, state, cfg = build_small(device, fp8=True)
+    B, Hpx, Wpx, Tt = 2, 128, 96, 24
+    Ti = (Hpx // 16) * (Wpx // 16)
+    oracle = build_oracle(state, cfg, True)
+    freqs = _freqs(oracle, Tt, Hpx, Wpx)
+    fd = (freqs[0].to(device), freqs[1].to(device))
+    a = [x.to(device) for x in small_inputs(B, Ti, Tt, cfg, seed=1)]
+    b = [x.to(device) for x in small_inputs(B, Ti, Tt, cfg, seed=2)]
+    with torch.no_grad():
+        want_b = model.forward_fused(*b, fd).clone()        # also warms up: workspace, attributes
+        static = [x.clone() for x in a]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                         # warm-up on the capture stream
+            model.forward_fused(*static, fd)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model.forward_fused(*static, fd)
+        want_a = model.forward_fused(*a, fd).clone()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want_a)
+        for s, x in zip(static, b):
+            s.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want_b)
