@@ -80,11 +80,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   const int r = lane & 31;
   const int hh = lane >> 5;
 
-  // grid: x = q block (fastest), y = head, z = batch.  Consecutive blocks share
-  // (b, h), i.e. the same K/V, which keeps K/V re-reads in L2.
-  const int qb = blockIdx.x;
-  const int head = blockIdx.y;
-  const int b = blockIdx.z;
+  // grid: x = q block (fastest), y = head, z = batch.  Workgroups are dealt to the 8 XCDs
+  // round robin by their linear id, and every XCD has its own L2: remap the ids so that each
+  // XCD owns a CONTIGUOUS range of (batch, head, q block) work, i.e. its ~64 resident
+  // workgroups stream the K/V of two heads instead of fourteen and re-reads hit its L2.
+  // Bijective for any grid size.
+  int qb, head, b;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = total >> 3, rem = total & 7, xcd = lin & 7;
+    const unsigned wid =
+        (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (lin >> 3);
+    qb = (int)(wid % gx);
+    const unsigned bh = wid / gx;
+    head = (int)(bh % gy);
+    b = (int)(bh / gy);
+  }
   const int hk = head / (p.H / p.Hk);
   const int q0 = qb * 128 + wave * 32;
 
