@@ -54,6 +54,11 @@ if mode == "txt":
     for (fp8, M, N, K) in [(False, 2048, 3072, 12288), (False, 2048, 12288, 3072), (True, 2048, 9216, 3072),
                            (True, 2048, 3072, 3072), (False, 16384, 3072, 12288), (True, 18432, 3072, 15360)]:
         bench(fp8, M, N, K)
+if mode == "narrow":
+    # N = 3072 outputs (12 tile columns): proj_out, to_out, FF2
+    for (fp8, M, N, K) in [(True, 18432, 3072, 15360), (True, 16384, 3072, 3072), (False, 16384, 3072, 12288),
+                           (True, 16384, 9216, 3072)]:
+        bench(fp8, M, N, K)
 if mode in ("bf16", "both"):
     for (M, N, K) in [(16384, 12288, 3072), (16384, 3072, 12288), (8192, 8192, 8192)]:
         bench(False, M, N, K)
