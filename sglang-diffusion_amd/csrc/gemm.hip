@@ -150,7 +150,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
               o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
             }
           }
-          *reinterpret_cast<u32x4*>(p.out + orow + n8) = o;
+          __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(p.out + orow + n8));
         }
       }
     }
