@@ -593,6 +593,20 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   return MI355_OK;
 }
 
+// 256x256 tiles (one workgroup per CU) or 128x128 (two per CU)?  Small ones when the big ones
+// would not cover three quarters of the CUs; otherwise whichever fills its rounds better, the small tile counted at its measured relative speed (0.8 of the big one for fp8, 0.7
+// for bf16): 2048 x 9216 fp8 is 288 big tiles = 1.125 rounds (93 us) but 2.25 rounds of small ones
+// (72 us).  sglang_diffusion_amd/models/flux_engine.py labels its launches with the same rule.
+bool use_big_tile(int64_t M, int64_t N, bool fp8) {
+  const int cus = resident_workgroups(128 * 1024);
+  const int64_t tb = ((M + 255) / 256) * ((N + 255) / 256);
+  const int64_t ts = ((M + 127) / 128) * ((N + 127) / 128);
+  if (tb < cus * 3 / 4) return false;  // too few big tiles to cover the chip: more, smaller ones
+  const double eff_b = (double)tb / (double)(((tb + cus - 1) / cus) * cus);
+  const double eff_s = (double)ts / (double)(((ts + 2 * cus - 1) / (2 * cus)) * (2 * cus));
+  return eff_b >= eff_s * (fp8 ? 0.8 : 0.7);
+}
+
 int check_common(const mi355_linear_args* a, const char* who) {
   MI355_REQUIRE(a->M == 0 || (a->a && a->w && a->out), "%s: null pointer", who);
   MI355_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "%s: bad shape M=%ld N=%ld K=%ld", who,
@@ -701,8 +715,7 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
     p.sb_sn = a->sb_sn;
   }
   // Tile choice: 256x256 (8 waves) when the grid still covers the chip, else 128x128.
-  const int64_t big_tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
-  const bool big = big_tiles >= 192;
+  const bool big = use_big_tile(a->M, a->N, a->fp8 != 0);
   if (a->block_scale)
     return big ? launch_gemm<1, 4, 2, 2, 4, true>(p, st) : launch_gemm<1, 2, 2, 2, 2, true>(p, st);
   if (a->fp8) {

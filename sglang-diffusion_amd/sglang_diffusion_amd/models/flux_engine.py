@@ -26,12 +26,35 @@ allocated once per (batch, sequence) shape.
 """
 from __future__ import annotations
 
+import functools
 from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from .. import _C
 from ..layers.quantization import FP8_DTYPE, Fp8LinearMethod, UnquantizedLinearMethod
+
+
+@functools.lru_cache(maxsize=None)
+def _cu_count(device_index: int) -> int:
+    return torch.cuda.get_device_properties(device_index).multi_processor_count
+
+
+@functools.lru_cache(maxsize=None)
+def _big_tile_rule(M: int, N: int, fp8: bool, cus: int) -> bool:
+    tb = ((M + 255) // 256) * ((N + 255) // 256)
+    ts = ((M + 127) // 128) * ((N + 127) // 128)
+    if tb < cus * 3 // 4:
+        return False
+    eff_b = tb / (-(-tb // cus) * cus)
+    eff_s = ts / (-(-ts // (2 * cus)) * (2 * cus))
+    return eff_b >= eff_s * (0.8 if fp8 else 0.7)
+
+
+def _uses_big_tile(M: int, N: int, fp8: bool, device) -> bool:
+    """The tile choice of csrc/gemm.hip (use_big_tile), for labelling launches in traces."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _big_tile_rule(M, N, bool(fp8), _cu_count(idx))
 
 
 def _is_block(lin) -> bool:
@@ -195,8 +218,7 @@ class FluxEngine:
     # ---------------------------------------------------------------------- helpers --
     def _lin(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
              gate=None, gate_rows=0, act=0, ldo=None, lda=None, f16_cols=None):
-        # same tile rule as csrc/gemm.hip: the 256x256 kernel when it yields >= 192 tiles
-        big = ((M + 255) // 256) * ((pk.N + 255) // 256) >= 192
+        big = _uses_big_tile(M, pk.N, pk.fp8, a.device)
         self._run(("gemm_fp8blk" if pk.block else "gemm_fp8" if pk.fp8 else "gemm_bf16")
                   + ("_256" if big else "_128"),
                   2.0 * M * pk.N * pk.K,
@@ -211,7 +233,7 @@ class FluxEngine:
         """Unquantised nn.Linear-style module (FF, embedders)."""
         w = mod.weight.data
         N, K = w.shape
-        big = ((M + 255) // 256) * ((N + 255) // 256) >= 192
+        big = _uses_big_tile(M, N, False, a.device)
         self._run("gemm_bf16" + ("_256" if big else "_128"), 2.0 * M * N * K,
                   2.0 * (M * K + N * K + M * N), _C.linear_ex, a, w,
                   out, M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldo=out.stride(0),
