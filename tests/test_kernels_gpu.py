@@ -453,6 +453,37 @@ def test_attention_over_key_halves_merges_to_the_whole(device):
     assert (la - lse_w).abs().max().item() <= 2e-5
 
 
+def test_attention_at_video_length(device):
+    """One sequence-parallel rank's attention of the HunyuanVideo configuration (3 of 24 heads
+    over 118 800 image + 256 text tokens): the merge property over a ragged key split, and
+    sampled query rows against an fp64 softmax(q K^T) V computed with torch on the device."""
+    B, S, H, D = 1, 118800 + 256, 3, 128
+    gen = torch.Generator(device=device).manual_seed(17)
+    q, k, v = ((torch.randn(B, S, H, D, generator=gen, device=device) * 1.2).bfloat16()
+               for _ in range(3))
+    scale = D ** -0.5
+    whole = torch.empty_like(q)
+    lse_w = torch.empty(B, H, S, dtype=torch.float32, device=device)
+    _C.attention(q, k, v, whole, lse_w, scale)
+    rows = torch.tensor([0, 31, 32, 127, 128, 59527, 118799, 118800, S - 1], device=device)
+    qs = q[0, rows].double().transpose(0, 1)                      # [H, rows, D]
+    sc = torch.einsum("hrd,shd->hrs", qs, k[0].double()) * scale
+    ref = torch.einsum("hrs,shd->rhd", torch.softmax(sc, dim=-1), v[0].double())
+    assert rel_l2(whole[0, rows], ref) <= 4e-3                    # 1e-3 bar + bf16 output rounding
+    ref_lse = torch.logsumexp(sc, dim=-1)                         # [H, rows]
+    assert (lse_w[0][:, rows].double() - ref_lse).abs().max().item() <= 1e-4
+    cut = 50001
+    parts = []
+    for sl in (slice(0, cut), slice(cut, S)):
+        o, l = torch.empty_like(whole), torch.empty_like(lse_w)
+        _C.attention(q, k[:, sl], v[:, sl], o, l, scale)
+        parts.append((o, l))
+    (oa, la), (ob, lb) = parts
+    _C.merge_attn_states(oa, la, oa, la, ob, lb)
+    assert rel_l2(oa, whole) <= 3e-3
+    assert (la - lse_w).abs().max().item() <= 5e-5
+
+
 def test_cfg_parallel_partial_product_is_the_eager_bf16_product(device):
     """The per-rank contribution of CFG parallelism, s * pred in bf16 (denoising.py:1438-1444),
     through the guidance-combine kernel with a zero second operand."""
