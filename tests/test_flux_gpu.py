@@ -200,7 +200,8 @@ def test_dp_batch_scheduler_on_the_hip_path(device):
         assert torch.equal(got, exp)
 
 
-def test_fused_step_replays_from_a_hip_graph(device):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_fused_step_replays_from_a_hip_graph(device, overlap):
     """A serving loop can capture the fused DiT forward once and replay it: every launch goes
     to the capturing stream, nothing synchronises, and the workspace is allocated before the
     capture.  The replay on NEW input values equals the eager call bit for bit."""
@@ -214,6 +215,11 @@ def test_fused_step_replays_from_a_hip_graph(device):
     b = [x.to(device) for x in small_inputs(B, Ti, Tt, cfg, seed=2)]
     with torch.no_grad():
         want_b = model.forward_fused(*b, fd).clone()        # also warms up: workspace, attributes
+        if overlap:
+            # text chain of the double blocks on the engine's second stream: forks from and
+            # rejoins the capturing stream, same bits as the one-stream schedule
+            model._engine.overlap_text = True
+            assert torch.equal(model.forward_fused(*b, fd), want_b)
         static = [x.clone() for x in a]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
