@@ -62,3 +62,9 @@ if mode == "narrow":
 if mode in ("bf16", "both"):
     for (M, N, K) in [(16384, 12288, 3072), (16384, 3072, 12288), (8192, 8192, 8192)]:
         bench(False, M, N, K)
+if mode == "gelu":
+    # what the tanh-GELU in the epilogue costs: FF1 (bf16) and proj_mlp (fp8), with and without
+    for (fp8, M, N, K) in [(False, 16384, 12288, 3072), (True, 18432, 12288, 3072)]:
+        for act in (0, 1):
+            print(f"act={act}", end="  ")
+            bench(fp8, M, N, K, act=act)
