@@ -228,3 +228,25 @@ def test_sgl_kernel_schemas_and_fake_impls():
     with pytest.raises(NotImplementedError):           # CPU tensors are never computed on
         sgl_kernel.sgl_per_token_quant_fp8(torch.zeros(2, 128, dtype=torch.bfloat16),
                                            torch.zeros(2, 128).to(torch.float8_e4m3fn), torch.zeros(2))
+
+
+def test_gemm_tile_rule_on_the_flux_shapes():
+    """The engine's mirror of the GEMM launcher's tile choice (it labels launches for the
+    per-class timing): 256x256 tiles unless they would cover under three quarters of the CUs
+    or fill their rounds clearly worse than 128x128 tiles fill theirs."""
+    from sglang_diffusion_amd.models.flux_engine import _big_tile_rule
+
+    cus = 256
+    # image stream and single blocks at B = 4: always the big tile
+    for (M, N, fp8) in [(16384, 9216, True), (18432, 12288, True), (18432, 3072, True),
+                        (16384, 12288, False), (16384, 3072, False)]:
+        assert _big_tile_rule(M, N, fp8, cus)
+    # text stream (M = 2048): q|k|v has 288 big tiles = 1.125 rounds -> small; FF1 stays big
+    assert not _big_tile_rule(2048, 9216, True, cus)
+    assert _big_tile_rule(2048, 12288, False, cus)
+    # too few big tiles to cover the chip
+    assert not _big_tile_rule(2048, 3072, True, cus)
+    assert not _big_tile_rule(2048, 3072, False, cus)
+    assert not _big_tile_rule(5, 64, True, cus)
+    # exactly full rounds of big tiles beat anything
+    assert _big_tile_rule(256 * 16, 256 * 16, True, cus)
