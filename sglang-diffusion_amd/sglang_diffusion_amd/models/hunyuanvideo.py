@@ -207,8 +207,13 @@ class MMSingleStreamBlock(nn.Module):
         _C.qk_norm_rope(q, k, w_q, w_k, w_q, w_k, 0, 1e-6, cos, sin, True)
         Ti = S - txt_len
         img_o, txt_o = self.attn(q[:, :Ti], k[:, :Ti], v[:, :Ti], q[:, Ti:], k[:, Ti:], v[:, Ti:])
-        attn = torch.cat((img_o, txt_o), dim=1).reshape(B, S, -1)
-        combined = torch.cat((attn, _gelu_tanh(lin1[:, :, 3 * D:])), dim=-1)
+        # linear2's input [attention | gelu(mlp)] is assembled in place: the activation kernel
+        # reads the MLP columns of lin1 and writes the right-hand columns of `combined` (row
+        # strides on both sides), the two attention outputs are copied into the left-hand ones
+        combined = torch.empty(B, S, D + self.mlp_hidden_dim, dtype=lin1.dtype, device=lin1.device)
+        _C.activation(combined.view(B * S, -1)[:, D:], lin1.view(B * S, -1)[:, 3 * D:], 1)
+        combined[:, :Ti, :D] = img_o.reshape(B, Ti, D)
+        combined[:, Ti:, :D] = txt_o.reshape(B, txt_len, D)
         out, _ = self.linear2(combined)
         return self.output_residual(out, gate, x)
 
