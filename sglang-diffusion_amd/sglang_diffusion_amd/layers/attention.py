@@ -333,6 +333,19 @@ class USPAttention(nn.Module):
         return torch.cat([torch.cat(parts, dim=2), out_shard], dim=1)
 
 
+def _append_tokens(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[B, Sa, H, D] followed by [B, Sb, H, D] along the token dimension.  When `b` already
+    sits right behind `a` in one buffer with the same strides (the two streams' slices of a
+    joint q|k|v projection) the result is a view of that buffer; otherwise a concatenation."""
+    if (a.dtype == b.dtype and a.device == b.device and a.stride() == b.stride()
+            and a.shape[0] == b.shape[0] and a.shape[2:] == b.shape[2:]
+            and b.data_ptr() == a.data_ptr() + a.shape[1] * a.stride(1) * a.element_size()
+            and (a.shape[0] == 1 or a.stride(0) >= (a.shape[1] + b.shape[1]) * a.stride(1))):
+        return torch.as_strided(a, (a.shape[0], a.shape[1] + b.shape[1]) + tuple(a.shape[2:]),
+                                a.stride(), a.storage_offset())
+    return torch.cat([a, b], dim=1)
+
+
 class UlyssesAttention(nn.Module):
     """layer.py:38-154: sequence-parallel attention with an optional REPLICATED token set.
 
@@ -384,9 +397,9 @@ class UlyssesAttention(nn.Module):
             assert replicated_k is not None and replicated_v is not None
             hp = H // P
             hs = slice(rank * hp, (rank + 1) * hp)
-            q = torch.cat([q, replicated_q[:, :, hs]], dim=1)
-            k = torch.cat([k, replicated_k[:, :, hs]], dim=1)
-            v = torch.cat([v, replicated_v[:, :, hs]], dim=1)
+            q = _append_tokens(q, replicated_q[:, :, hs])
+            k = _append_tokens(k, replicated_k[:, :, hs])
+            v = _append_tokens(v, replicated_v[:, :, hs])
         out = self.attn_impl.forward(q, k, v, md)
         rep_out = None
         if replicated_q is not None:

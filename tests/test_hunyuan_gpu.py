@@ -220,3 +220,31 @@ def test_checkpoint_loads_into_hbm_and_runs(device, tmp_path, fp8):
         a = loaded(x, enc, t, guid)
         b = src(x, enc, t, guid)
     assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+
+
+def test_adjacent_stream_slices_reach_the_kernel_without_a_copy(device):
+    """UlyssesAttention on one rank: when the replicated (text) tokens sit right behind the main
+    tokens in one q|k|v buffer the kernel reads that buffer; separate tensors are concatenated.
+    Same bits either way."""
+    from sglang_diffusion_amd.layers.attention import (Mi355AttentionMetadataBuilder,
+                                                       UlyssesAttention, _append_tokens)
+    from sglang_diffusion_amd.layers.forward_context import set_forward_context
+
+    B, Ti, Tt, H, D = 2, 200, 40, 2, 128
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(B, Ti + Tt, 3, H, D, generator=g).bfloat16().to(device)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    joint = _append_tokens(q[:, :Ti], q[:, Ti:])
+    assert joint.data_ptr() == q.data_ptr() and joint.shape == q.shape and torch.equal(joint, q)
+    apart = _append_tokens(q[:, :Ti], q[:, Ti:].clone())
+    assert apart.data_ptr() != q.data_ptr() and torch.equal(apart, q)
+    # a gap between the two slices, or a different head subset, is not adjacency
+    assert _append_tokens(q[:, :Ti - 1], q[:, Ti:]).shape[1] == Ti + Tt - 1
+    assert _append_tokens(q[:, :Ti - 1], q[:, Ti:]).data_ptr() != q.data_ptr()
+    attn = UlyssesAttention(num_heads=H, head_size=D)
+    md = Mi355AttentionMetadataBuilder().build(current_timestep=0)
+    with set_forward_context(current_timestep=0, attn_metadata=md):
+        a_img, a_txt = attn(q[:, :Ti], k[:, :Ti], v[:, :Ti], q[:, Ti:], k[:, Ti:], v[:, Ti:])
+        b_img, b_txt = attn(q[:, :Ti], k[:, :Ti], v[:, :Ti],
+                            q[:, Ti:].clone(), k[:, Ti:].clone(), v[:, Ti:].clone())
+    assert torch.equal(a_img, b_img) and torch.equal(a_txt, b_txt)
