@@ -1,8 +1,8 @@
 // Flash-attention forward for gfx950: dense softmax(Q K^T * scale) V, bf16
 // in/out, fp32 scores/softmax/accumulation, online softmax over 64-key tiles.
 //
-// Shape of the computation (one workgroup = 4 wavefronts = 128 query rows of
-// one (batch, head); each wavefront owns 32 query rows):
+// Shape of the computation (one workgroup = 4 or 8 wavefronts = 128 or 256 query rows of
+// one (batch, head), sharing the K/V tiles in LDS; each wavefront owns 32 query rows):
 //   S^T[key][q] = mfma_32x32x16(A = K tile fragment, B = Q fragment)
 //       -> the query sits on the LANE, the keys in registers, so the row max /
 //          row sum are in-register reductions plus ONE exchange between lane l
@@ -60,14 +60,14 @@ __device__ __forceinline__ int v_swz(int key) { return ((key & 3) << 2) | ((key 
 // D = head size (128 or 64).  KV tile = 64 keys.
 // F16: V holds IEEE half values and P is rounded to half (11 significant bits instead of
 // bf16's 8) before the PV product; Q, K and the output stay bf16.
-template <int D, bool TRREAD, bool F16>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+template <int D, bool TRREAD, bool F16, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
   constexpr int KV = 64;
   constexpr int ROWB = D * 2;                // bytes per K/V row
   constexpr int CPR = ROWB / 16;             // 16-B chunks per row (16 or 8)
   constexpr int TILE_BYTES = KV * ROWB;      // one K or V tile
   constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-  constexpr int PIECES = 2 * TILE_BYTES / 1024 / 4;  // 1-KiB DMA pieces per wave per stage
+  constexpr int PIECES = 2 * TILE_BYTES / 1024 / NW;  // 1-KiB DMA pieces per wave per stage
   constexpr int KSTEPS = D / 16;             // QK^T k-steps
   constexpr int DVB = D / 32;                // 32-wide dv blocks
   static_assert(D == 128 || D == 64, "head size");
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     b = (int)(bh / gy);
   }
   const int hk = head / (p.H / p.Hk);
-  const int q0 = qb * 128 + wave * 32;
+  const int q0 = qb * (NW * 32) + wave * 32;
 
   // ---- Q fragments: B operand, lane -> query row r, d = 16s + 8hh + 0..7 ----
   bf16x8 qf[KSTEPS];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   unsigned int voff[PIECES];
 #pragma unroll
   for (int i = 0; i < PIECES; ++i) {
-    const int piece = wave + 4 * i;             // 0 .. 2*TILE_BYTES/1024-1
+    const int piece = wave + NW * i;             // 0 .. 2*TILE_BYTES/1024-1
     const int lin = piece * 64 + lane;          // 16-B slot index in [K|V] stage image
     const int slot = lin % (TILE_BYTES / 16);   // slot within its tile
     const bool isv = i >= PIECES / 2;           // == (lin >= TILE_BYTES / 16)
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       const unsigned char* vt0 = vbase + (int64_t)(k0 / KV) * v_tile_step;
 #pragma unroll
       for (int i = 0; i < PIECES; ++i) {
-        const int piece = wave + 4 * i;
+        const int piece = wave + NW * i;
         const unsigned char* src = (i >= PIECES / 2 ? vt0 : kt0) + voff[i];
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
                                          (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16,
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     } else {
 #pragma unroll
       for (int i = 0; i < PIECES; ++i) {
-        const int piece = wave + 4 * i;
+        const int piece = wave + NW * i;
         int key = k0 + prow[i];
         if (key >= p.Sk) key = p.Sk - 1;
         const unsigned char* src = i >= PIECES / 2
@@ -436,8 +436,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
-template <int D, bool TRREAD, bool F16>
+template <int D, bool TRREAD, bool F16, int NW = 4>
 int launch_attn(const AttnParams& p, hipStream_t st) {
+  if constexpr (NW == 4) {
+    // Eight waves (256 query rows) share each K/V tile once the launch still has a workgroup
+    // for every CU: same occupancy (one 8-wave workgroup per CU instead of two 4-wave ones),
+    // same results to the bit, half the L2 -> LDS traffic.
+    static std::atomic<int> cus{0};
+    int n = cus.load(std::memory_order_relaxed);
+    if (n == 0) {
+      int d = 0;
+      (void)hipGetDevice(&d);
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0)
+        n = 256;
+      cus.store(n, std::memory_order_relaxed);
+    }
+    if (((p.Sq + 255) / 256) * (int64_t)p.H * p.B >= n) return launch_attn<D, TRREAD, F16, 8>(p, st);
+  }
   constexpr int LDS = 2 * 2 * 64 * D * 2;
   // the LDS limit is a per-device function attribute: remember which devices have it
   // callers may launch from several host threads: the per-device flags are atomic (a lost
@@ -446,7 +461,7 @@ int launch_attn(const AttnParams& p, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
-  auto kfn = attn_fwd_kernel<D, TRREAD, F16>;
+  auto kfn = attn_fwd_kernel<D, TRREAD, F16, NW>;
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -456,7 +471,7 @@ int launch_attn(const AttnParams& p, hipStream_t st) {
     }
     attr_devices.fetch_or(dev_bit, std::memory_order_release);
   }
-  dim3 grid((unsigned)((p.Sq + 127) / 128), (unsigned)p.H, (unsigned)p.B), block(256);
+  dim3 grid((unsigned)((p.Sq + NW * 32 - 1) / (NW * 32)), (unsigned)p.H, (unsigned)p.B), block(NW * 64);
   hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
   MI355_CHECK_LAUNCH("flash_attn_fwd");
   return MI355_OK;

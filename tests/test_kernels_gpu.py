@@ -453,6 +453,29 @@ def test_attention_over_key_halves_merges_to_the_whole(device):
     assert (la - lse_w).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("D,half_v", [(128, True), (128, False), (64, True)])
+def test_attention_workgroup_width_does_not_change_the_bits(device, D, half_v):
+    """Launches with a workgroup for every CU run 256 query rows per workgroup, smaller ones
+    128: a slice of the queries (a small launch) must give the very rows of the big launch."""
+    B, S, H = 4, 1000, 24                      # 4 * 24 * ceil(1000 / 256) = 384 workgroups
+    gen = torch.Generator(device=device).manual_seed(23)
+    q, k, v = ((torch.randn(B, S, H, D, generator=gen, device=device) * 1.3).bfloat16()
+               for _ in range(3))
+    vv = v.to(torch.float16) if half_v else v
+    scale = D ** -0.5
+    big = torch.empty_like(q)
+    lse_big = torch.empty(B, H, S, dtype=torch.float32, device=device)
+    _C.flash_attn_fwd(q, k, vv, big, lse_big, scale, v_is_f16=half_v)
+    for (b, lo, hi) in [(0, 0, 128), (3, 700, 1000), (1, 250, 390)]:
+        qs = q[b:b + 1, lo:hi, :2]             # 2 heads, <= 3 query blocks: a small launch
+        small = torch.empty_like(qs)
+        lse_small = torch.empty(1, 2, hi - lo, dtype=torch.float32, device=device)
+        _C.flash_attn_fwd(qs, k[b:b + 1, :, :2], vv[b:b + 1, :, :2], small, lse_small, scale,
+                          v_is_f16=half_v)
+        assert torch.equal(small, big[b:b + 1, lo:hi, :2])
+        assert torch.equal(lse_small, lse_big[b:b + 1, :2, lo:hi])
+
+
 def test_attention_at_video_length(device):
     """One sequence-parallel rank's attention of the HunyuanVideo configuration (3 of 24 heads
     over 118 800 image + 256 text tokens): the merge property over a ragged key split, and
