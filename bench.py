@@ -9,17 +9,30 @@ bf16 everywhere else: the configuration the metric is quoted on.  With N > 1 eve
 its own batch (data parallel over requests, no collective inside a step): weak scaling, the
 reported value is the whole-job images/s = N*B / (50 * step time).
 
+Launch.  `python bench.py --gpus N` with N > 1 starts its own N rank processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, tcp rendezvous
+on 127.0.0.1 as the reference's per-GPU scheduler processes do,
+python/sglang/multimodal_gen/runtime/launch_server.py:61-187, managers/gpu_worker.py:92-111) and
+waits for them; the parent never imports torch or touches the GPU.  Under an external launcher
+(torch.distributed.run: WORLD_SIZE already set) the process IS a rank.
+
 One JSON line is printed by rank 0.  Besides the contract fields it carries
   roofline     : the dominant kernel (the 256x256-tile fp8 MFMA GEMM), algorithmic FLOP per
                  launch / its average duration measured with events on the launch stream,
                  against the dense fp8 MFMA peak;
-  cpu_baseline : the CPU oracle timed on this host on a bounded sample of the same workload.
+  cpu_baseline : the CPU oracle timed on this host on a bounded sample of the same workload;
+  c4           : the fixed-size job "32 requests with true CFG (guidance 3.5, negative
+                 prompt) = 64 DiT samples per step" drained through DataParallelBatchScheduler
+                 over the N ranks, requests sent from rank 0 and final latents gathered back
+                 inside the timed region: STRONG scaling (the same 32 images at every N).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,8 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "sglang-diffusion_amd"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# torch is imported by the rank processes only (inside main): the launcher parent must stay
+# free of anything that could initialise the GPU before its children start
 
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA, MI355X
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
@@ -45,10 +58,54 @@ def flux_step_flops(B: int, S: int = 4608, D: int = 3072, n_double: int = 19, n_
     return dict(fp8=float(fp8), bf16=float(bf16), attn=float(attn), total=float(fp8 + bf16 + attn))
 
 
+def launch_ranks(n: int, argv, timeout_s: float = 3300.0) -> int:
+    """Start `n` copies of this script as rank processes and wait for them.  Returns the exit
+    code for the parent: 0 when every rank exited 0, else the first failing rank's code (the
+    remaining ranks are terminated by PID).  Rank 0 inherits stdout (it prints the JSON line);
+    the other ranks' stdout goes to stderr."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv),
+                                      env=env, stdout=None if r == 0 else sys.stderr))
+    deadline = time.time() + timeout_s
+    rc = 0
+    live = dict(enumerate(procs))
+    while live:
+        for r, p in list(live.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del live[r]
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+        if (rc != 0 or time.time() > deadline) and live:
+            for p in live.values():
+                p.terminate()
+            for p in live.values():
+                try:
+                    p.wait(20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if rc == 0:
+                rc = 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
 def cpu_baseline(seconds_hint: float = 20.0):
     """Oracle (CPU restatement of the reference eager path) on a bounded sample: one double +
     one single block of the FULL-SIZE Flux.1-dev DiT at B = 1, fp8 linears emulated as the
     reference does on CPU.  Scaled to a whole step by algorithmic FLOP."""
+    import torch
+
     from oracle.flux_oracle import FluxOracle
 
     torch.manual_seed(0)
@@ -134,7 +191,38 @@ def main():
                          "instead of random-init weights; \"data\" then says so")
     ap.add_argument("--layers", type=int, nargs=2, default=None,
                     help="(debug) override #double #single blocks; the result is then NOT the metric")
+    ap.add_argument("--no-c4", action="store_true",
+                    help="skip the fixed-size 32-CFG-request job through the batch scheduler")
+    ap.add_argument("--c4-requests", type=int, default=32)
+    ap.add_argument("--c4-steps", type=int, default=None,
+                    help="denoise steps per micro-batch of the c4 job (default: --steps)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, rendezvous over gloo on the host, all-reduce the "
+                         "rank numbers and print {launch_check, n_gpus, rank_sum}: tests the "
+                         "launcher where there is no GPU")
+    ap.add_argument("--launch-check-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
+
+    if args.launch_check:
+        from sglang_diffusion_amd.runtime.parallel import init_distributed
+
+        rank, world, local = init_distributed("gloo")
+        if rank == args.launch_check_fail_rank:
+            raise SystemExit(3)
+        t = torch.tensor([rank], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(t.item()),
+                              "local_rank": local}))
+        return
 
     from sglang_diffusion_amd.layers.quantization import Fp8Config
     from sglang_diffusion_amd.models.flux import FluxTransformer2DModel, flux_dev_config
@@ -279,6 +367,51 @@ def main():
         roofline["traffic"] = None
     fl = flux_step_flops(B, n_double=cfg.num_layers, n_single=cfg.num_single_layers)
 
+    # ---- the fixed-size CFG job through the batch scheduler (strong scaling) -----------------
+    c4 = None
+    if not args.no_c4 and not args.schnell:
+        from sglang_diffusion_amd.runtime.batch_scheduler import DataParallelBatchScheduler
+
+        n_req, c4_steps = args.c4_requests, args.c4_steps or args.steps
+        sch = DataParallelBatchScheduler(stage, rank=rank, world_size=world, max_samples_per_step=8,
+                                         queue_on_rank0=True)
+        # rank 0 owns the queue: 32 requests of one image each, cond + uncond prompt, true CFG 3.5
+        queue = [make_synthetic_request(1, 1024, 1024, NUM_INFERENCE_STEPS, device=dev,
+                                        seed=1000 + i, true_cfg=True, guidance_scale=3.5)
+                 for i in range(n_req)] if rank == 0 else []
+
+        def drain(k, timing=None):
+            for r in queue:
+                sch.add_request(r)
+            return sch.run(num_steps=k, timing=timing)
+
+        drain(1)  # untimed: workspace for 8-sample micro-batches, communicator set-up
+        phases = {}
+        barrier()
+        t0 = time.perf_counter()
+        finals = drain(c4_steps, phases)
+        barrier()
+        c4_elapsed = time.perf_counter() - t0
+        ph = torch.tensor([c4_elapsed, phases.get("scatter_s", 0.0), phases.get("compute_s", 0.0),
+                           phases.get("gather_s", 0.0)], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+        c4_elapsed, sc_s, cp_s, ga_s = ph.tolist()
+        if rank == 0:
+            assert len(finals) == n_req and all(bool(torch.isfinite(f.float()).all()) for f in finals)
+            full_job_s = sc_s + ga_s + cp_s * NUM_INFERENCE_STEPS / c4_steps
+            c4 = {"workload": f"{n_req} requests x (cond + uncond), true CFG scale 3.5, 1024x1024: "
+                              f"{2 * n_req} DiT samples per step, micro-batches of 8 samples, "
+                              "requests sent from rank 0 and final latents gathered to rank 0",
+                  "scaling": "strong", "n_gpus": world, "requests": n_req,
+                  "dit_samples_per_gpu": 2 * n_req / world, "steps_run": c4_steps,
+                  "elapsed_s": c4_elapsed, "scatter_s": sc_s, "compute_s": cp_s, "gather_s": ga_s,
+                  "ms_per_step_per_microbatch": cp_s * 1e3 / c4_steps / max(1, -(-2 * n_req // world // 8)),
+                  "images_per_s": n_req / full_job_s,
+                  "images_per_s_note": (f"{n_req} images / (scatter + gather + compute x "
+                                        f"{NUM_INFERENCE_STEPS}/{c4_steps}); each image costs 2 DiT "
+                                        "samples per step, so x2 compares with `value`")}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -313,7 +446,7 @@ def main():
         "mfma_utilisation_vs_fp8_peak": fl["total"] / step_s / 1e12 / PEAK_FP8_TFLOPS,  # per GPU
         "mixed_roofline_min_ms": (fl["fp8"] / (PEAK_FP8_TFLOPS * 1e12)
                                   + (fl["bf16"] + fl["attn"]) / (PEAK_BF16_TFLOPS * 1e12)) * 1e3,
-        "roofline": roofline, "breakdown": breakdown, "cpu_baseline": cpu,
+        "roofline": roofline, "breakdown": breakdown, "cpu_baseline": cpu, "c4": c4,
     }
     print(json.dumps(out))
     if world > 1:

@@ -39,6 +39,14 @@ def shard_requests(num_requests: int, world_size: int, rank: int) -> range:
     return range(start, start + base + (1 if rank < rem else 0))
 
 
+def _wire(t: torch.Tensor, group=None) -> torch.Tensor:
+    """The tensor a collective of `group` can carry: gloo moves host memory only, so device
+    tensors are staged through the host there (RCCL takes them as they are)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        return t.cpu()
+    return t
+
+
 def gather_latents(local: torch.Tensor, counts: Sequence[int], group=None) -> Optional[torch.Tensor]:
     """Gather per-rank final latents [n_r, ...] to rank 0 (once per batch).  Ranks may hold
     different request counts: pad to the maximum, all_gather, trim."""
@@ -48,27 +56,112 @@ def gather_latents(local: torch.Tensor, counts: Sequence[int], group=None) -> Op
     nmax = max(counts)
     pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
+    pad = _wire(pad, group)
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     if dist.get_rank(group) != 0:
         return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(local.device)
+
+
+_REQ_TENSORS = ("latents", "prompt_embeds", "pooled_embeds", "negative_prompt_embeds",
+                "neg_pooled_embeds")
+
+
+def scatter_requests(reqs, assign_fn, group=None, src: int = 0, device=None):
+    """Send every rank its share of a request list that only rank `src` of `group` holds.
+
+    `reqs` is the list on `src` and None elsewhere; `assign_fn(costs) -> [[positions], ...]`
+    maps per-request DiT-sample costs to ranks.  The scalar fields and tensor shapes of the
+    whole list travel as ONE broadcast object (the reference broadcasts each pickled request to
+    every rank, managers/scheduler.py:291-314); a request's tensors go point to point to the one
+    rank that runs it, all sends of a rank batched.  Returns (meta, mine): `meta[i]` describes
+    request i on every rank (rank, batch, latent shape/dtype), `mine` maps this rank's
+    positions to Req objects on `device` (default: where rank `src` keeps them)."""
+    import dataclasses
+
+    from .denoise import Req
+
+    me = dist.get_rank(group)
+    box = [None]
+    if me == src:
+        costs = [r.batch_size * (2 if r.do_classifier_free_guidance else 1) for r in reqs]
+        parts = assign_fn(costs)
+        owner = {i: rk for rk, p in enumerate(parts) for i in p}
+        scalars = [f.name for f in dataclasses.fields(Req) if f.name not in _REQ_TENSORS]
+        box[0] = [dict(rank=owner[i], batch=r.batch_size, shape=tuple(r.latents.shape[1:]),
+                       dtype=r.latents.dtype,
+                       scalars={k: getattr(r, k) for k in scalars},
+                       tensors={k: (tuple(getattr(r, k).shape), getattr(r, k).dtype)
+                                for k in _REQ_TENSORS if getattr(r, k) is not None},
+                       device=str(r.latents.device))
+                  for i, r in enumerate(reqs)]
+    dist.broadcast_object_list(box, src=_global_rank(group, src), group=group)
+    meta = box[0]
+    if device is None:
+        device = torch.device(meta[0]["device"]) if meta else torch.device("cpu")
+    on_host = dist.get_backend(group) == "gloo"
+    ops, mine, landing = [], {}, []
+    for i, m in enumerate(meta):
+        if me == src and m["rank"] == src:
+            mine[i] = reqs[i]
+        elif me == src:
+            for k in m["tensors"]:
+                t = getattr(reqs[i], k).contiguous()
+                ops.append(dist.P2POp(dist.isend, t.cpu() if on_host else t,
+                                      _global_rank(group, m["rank"]), group))
+        elif me == m["rank"]:
+            got = {}
+            for k, (shape, dtype) in m["tensors"].items():
+                got[k] = torch.empty(shape, dtype=dtype, device="cpu" if on_host else device)
+                ops.append(dist.P2POp(dist.irecv, got[k], _global_rank(group, src), group))
+            landing.append((i, got))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for i, got in landing:
+        mine[i] = Req(**{k: v.to(device) for k, v in got.items()}, **meta[i]["scalars"])
+    slim = [dict(rank=m["rank"], batch=m["batch"], shape=m["shape"], dtype=m["dtype"]) for m in meta]
+    return slim, mine
+
+
+def _global_rank(group, group_rank: int) -> int:
+    return dist.get_global_rank(group, group_rank) if group is not None else group_rank
 
 
 def ulysses_all_to_all(x: torch.Tensor, group, scatter_dim: int, gather_dim: int) -> torch.Tensor:
     """[B, S_local, H, D] <-> [B, S, H_local, D] exchange (layers/usp.py:49-158): split
     `scatter_dim` into P parts, send part p to rank p, concatenate what arrives along
     `gather_dim`.  One all_to_all_single per tensor; over xGMI every rank talks to all 7
-    peers at once, which is the pattern the point-to-point fabric is built for."""
+    peers at once, which is the pattern the point-to-point fabric is built for.
+
+    Copies: the send buffer is the input itself when its P parts are already contiguous
+    blocks (B = 1 and the sequence is scattered), else ONE packing copy; the received blocks
+    are the result itself when B = 1 and the sequence is gathered (a view), else ONE
+    interleaving copy."""
     P = dist.get_world_size(group)
     if P == 1:
         return x
+    if x.dim() != 4 or {scatter_dim, gather_dim} != {1, 2}:
+        raise ValueError("ulysses_all_to_all exchanges dims 1 (sequence) and 2 (heads) of [B, S, H, D]")
     if x.shape[scatter_dim] % P:
         raise ValueError(f"dim {scatter_dim} of size {x.shape[scatter_dim]} not divisible by {P}")
-    parts = torch.stack(x.chunk(P, dim=scatter_dim), dim=0).contiguous()
-    recv = torch.empty_like(parts)
-    dist.all_to_all_single(recv, parts, group=group)
-    return torch.cat(list(recv.unbind(0)), dim=gather_dim)
+    B, S, H, D = x.shape
+    if scatter_dim == 2:   # heads out, sequence in: [B, S, H, D] -> [B, P*S, H/P, D]
+        send = x.reshape(B, S, P, H // P, D).permute(2, 0, 1, 3, 4).contiguous()  # [P, B, S, H/P, D]
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+        if B == 1:
+            return recv.view(1, P * S, H // P, D)
+        return recv.permute(1, 0, 2, 3, 4).reshape(B, P * S, H // P, D)
+    # sequence out, heads in: [B, S, H, D] -> [B, S/P, P*H, D]
+    if B == 1 and x.is_contiguous():
+        send = x.view(P, 1, S // P, H, D)                                       # already P blocks
+    else:
+        send = x.reshape(B, P, S // P, H, D).permute(1, 0, 2, 3, 4).contiguous()
+    recv = torch.empty((P, B, S // P, H, D), dtype=x.dtype, device=x.device)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv.permute(1, 2, 0, 3, 4).reshape(B, S // P, P * H, D)
 
 
 def _hip_attention(q, k, v, scale):

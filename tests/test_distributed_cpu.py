@@ -12,7 +12,6 @@ import torch.multiprocessing as mp
 from sglang_diffusion_amd.runtime.batch_scheduler import DataParallelBatchScheduler, merge_requests
 from sglang_diffusion_amd.runtime.parallel import (cfg_parallel_combine, gather_latents,
                                                    init_distributed, ring_attention,
-                                                   shard_requests,
                                                    ulysses_all_to_all)
 from sglang_diffusion_amd.runtime.synthetic import make_synthetic_request
 
@@ -67,14 +66,24 @@ def test_gather_latents_uneven_counts():
 
 
 def _ulysses_case(rank):
-    B, S, H, D = 2, 6, 4, 8
-    full = torch.arange(B * S * H * D, dtype=torch.float32).view(B, S, H, D)
-    local = full[:, rank * S // WORLD:(rank + 1) * S // WORLD].contiguous()   # sequence shard
     g = dist.group.WORLD
-    heads = ulysses_all_to_all(local, g, scatter_dim=2, gather_dim=1)          # -> all S, H/P heads
-    ok_fwd = torch.equal(heads, full[:, :, rank * H // WORLD:(rank + 1) * H // WORLD])
-    back = ulysses_all_to_all(heads, g, scatter_dim=1, gather_dim=2)           # inverse exchange
-    ok_back = torch.equal(back, local)
+    ok_fwd = ok_back = True
+    # B = 1 takes the copy-free views, B = 2 the packed form; a strided input (a slice of a
+    # fused q|k|v buffer) must give the same result as a dense one
+    for B, strided in ((2, False), (1, False), (1, True), (2, True)):
+        S, H, D = 6, 4, 8
+        full = torch.arange(B * S * H * D, dtype=torch.float32).view(B, S, H, D)
+        local = full[:, rank * S // WORLD:(rank + 1) * S // WORLD]             # sequence shard
+        if strided:
+            buf = torch.zeros(B, S // WORLD, 3, H, D)
+            buf[:, :, 1] = local
+            local = buf[:, :, 1]
+        else:
+            local = local.contiguous()
+        heads = ulysses_all_to_all(local, g, scatter_dim=2, gather_dim=1)      # -> all S, H/P heads
+        ok_fwd &= torch.equal(heads, full[:, :, rank * H // WORLD:(rank + 1) * H // WORLD])
+        back = ulysses_all_to_all(heads, g, scatter_dim=1, gather_dim=2)       # inverse exchange
+        ok_back &= torch.equal(back, local)
     try:
         ulysses_all_to_all(torch.zeros(1, 3, 3, 2), g, scatter_dim=2, gather_dim=1)
         raised = False
@@ -105,18 +114,60 @@ def _dp_case(rank):
     sch = DataParallelBatchScheduler(_FakeStage(), rank=rank, world_size=WORLD, max_samples_per_step=3)
     for r in _queue():
         sch.add_request(r)
-    mine = list(sch.local_slice(5))
     out = sch.run()
-    return mine, (None if out is None else out.float())
+    return None if out is None else [o.float() for o in out]
 
 
 def test_dp_scheduler_two_ranks_equals_serial():
     ret = _run(_dp_case)
-    assert ret[0][0] == list(shard_requests(5, WORLD, 0)) == [0, 1, 2]
-    assert ret[1][0] == [3, 4]
-    assert ret[1][1] is None
-    expect = torch.cat([_FakeStage().forward(merge_requests([r])).latents for r in _queue()], dim=0)
-    assert torch.equal(ret[0][1], expect.float())
+    assert ret[1] is None
+    expect = [_FakeStage().forward(merge_requests([r])).latents for r in _queue()]
+    assert len(ret[0]) == len(expect)
+    for o, e in zip(ret[0], expect):
+        assert torch.equal(o, e.float())
+
+
+def _mixed_queue(with_cfg=True):
+    """Two latent shapes, plain and CFG requests interleaved: costs 1,2,1,4,1,2,2."""
+    out = []
+    for s, (b, hw, cfg) in enumerate([(1, 64, False), (1, 64, True), (1, 128, False), (2, 64, True),
+                                      (1, 128, False), (2, 64, False), (1, 128, True)]):
+        out.append(make_synthetic_request(b, height=hw, width=hw, num_inference_steps=2, device="cpu",
+                                          seed=s, text_len=4, joint_dim=8, pooled_dim=4,
+                                          true_cfg=cfg and with_cfg))
+        out[-1].request_ids = [f"r{s}"]
+    return out
+
+
+def _dp_mixed_case(rank, on_rank0):
+    sch = DataParallelBatchScheduler(_FakeStage(), rank=rank, world_size=WORLD, max_samples_per_step=4,
+                                     queue_on_rank0=on_rank0)
+    if not on_rank0 or rank == 0:
+        for r in _mixed_queue():
+            sch.add_request(r)
+    out = sch.run()
+    return None if out is None else [o.float() for o in out]
+
+
+def _dp_mixed_replicated(rank):
+    return _dp_mixed_case(rank, False)
+
+
+def _dp_mixed_scattered(rank):
+    return _dp_mixed_case(rank, True)
+
+
+@pytest.mark.parametrize("case", [_dp_mixed_replicated, _dp_mixed_scattered])
+def test_dp_scheduler_mixed_shapes_and_cfg_costs(case):
+    """Requests of two latent shapes and uneven CFG costs: one gather per shape returns every
+    request's latents to rank 0 in queue order, whether every rank was handed the queue or rank
+    0 alone held it and sent the other rank its share."""
+    ret = _run(case)
+    assert ret[1] is None
+    expect = [_FakeStage().forward(merge_requests([r])).latents for r in _mixed_queue()]
+    assert [tuple(o.shape) for o in ret[0]] == [tuple(e.shape) for e in expect]
+    for o, e in zip(ret[0], expect):
+        assert torch.equal(o, e.float())
 
 
 def _ring_case(rank):

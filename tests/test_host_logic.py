@@ -14,7 +14,8 @@ from sglang_diffusion_amd.models.scheduler import (FlowMatchEulerDiscreteSchedul
                                                    prepare_mu, prepare_sigmas)
 from sglang_diffusion_amd.runtime import pipeline_config as P
 from sglang_diffusion_amd.runtime.batch_scheduler import (DataParallelBatchScheduler,
-                                                          merge_requests, plan_microbatches)
+                                                          assign_requests, merge_requests,
+                                                          plan_microbatches, request_cost)
 from sglang_diffusion_amd.runtime.denoise import Req
 from sglang_diffusion_amd.runtime.parallel import shard_requests
 from sglang_diffusion_amd.runtime.synthetic import make_synthetic_request
@@ -87,9 +88,92 @@ def test_dp_scheduler_single_rank_matches_per_request_runs():
     for r in reqs:
         sch.add_request(r)
     outs = sch.run()
-    assert len(sch.queue) == 0 and len(outs) == len(reqs)
+    assert len(sch.waiting_queue) == 0 and len(outs) == len(reqs)
     for o, e in zip(outs, expect):
         assert torch.equal(o, e)
+
+
+def test_assign_requests_balances_dit_sample_cost():
+    # 4 CFG requests (2 samples each) + 4 plain ones on 2 ranks: 6 samples per rank, not 4 + 8
+    costs = [2, 2, 2, 2, 1, 1, 1, 1]
+    parts = assign_requests(costs, 2)
+    assert sorted(i for p in parts for i in p) == list(range(8))
+    assert [sum(costs[i] for i in p) for p in parts] == [6, 6]
+    assert all(p == sorted(p) for p in parts)                    # queue order inside a rank
+    # equal costs: the C4 case, 32 CFG pairs over 8 ranks = 4 requests = 8 samples each
+    parts = assign_requests([2] * 32, 8)
+    assert [len(p) for p in parts] == [4] * 8
+    # uneven CFG mix: the heaviest rank is within one request of the mean
+    costs = [2, 1, 1, 2, 2, 1, 2, 1, 1, 1, 2]
+    for world in (2, 3, 4, 8):
+        loads = [sum(costs[i] for i in p) for p in assign_requests(costs, world)]
+        assert sum(loads) == sum(costs) and max(loads) - min(loads) <= 2
+    assert assign_requests([], 4) == [[], [], [], []]
+    assert request_cost(_req(3, cfg=True)) == 6 and request_cost(_req(3)) == 3
+
+
+def test_merge_requests_carries_every_stage_option():
+    a, b = _req(1, cfg=True, seed=1), _req(1, cfg=True, seed=2)
+    for r, rid in ((a, "a"), (b, "b")):
+        r.guidance_rescale, r.request_ids = 0.7, [rid]
+    m = merge_requests([a, b])
+    assert m.guidance_rescale == 0.7 and m.cfg_normalization == 0.0 and m.request_ids == ["a", "b"]
+    b.guidance_rescale = 0.0                                     # differing options never merge
+    with pytest.raises(ValueError):
+        merge_requests([a, b])
+    assert plan_microbatches([a, b], max_samples=8) == [[0], [1]]
+    # the norm cap is a whole-batch norm: such requests run alone even when they match
+    c, d = _req(1, cfg=True, seed=3), _req(1, cfg=True, seed=4)
+    c.cfg_normalization = d.cfg_normalization = 1.0
+    assert plan_microbatches([c, d], max_samples=8) == [[0], [1]]
+    with pytest.raises(ValueError):
+        merge_requests([c, d])
+    assert merge_requests([c]).cfg_normalization == 1.0
+
+
+class _OptionStage:
+    """A stand-in denoise stage whose result depends on the two post-CFG options the way the
+    real ones do: guidance_rescale per sample, cfg_normalization through a whole-batch norm."""
+
+    def forward(self, req: Req, num_steps=None):
+        x = req.latents.float() * (1.0 + req.guidance_rescale)
+        if req.cfg_normalization and req.cfg_normalization > 0:
+            x = x * req.cfg_normalization / x.norm()
+        req.latents = x
+        return req
+
+
+def test_scheduler_equals_stage_forward_with_post_cfg_options():
+    def queue():
+        out = []
+        for s in range(4):
+            r = _req(1, cfg=True, seed=s)
+            r.guidance_rescale, r.cfg_normalization = 0.7, 1.5
+            out.append(r)
+        return out
+
+    expect = [_OptionStage().forward(r).latents for r in queue()]
+    sch = DataParallelBatchScheduler(_OptionStage(), max_samples_per_step=8)
+    for r in queue():
+        sch.add_request(r)
+    for o, e in zip(sch.run(), expect):
+        assert torch.equal(o, e)
+
+
+def test_get_next_batch_to_run_admits_between_micro_batches():
+    sch = DataParallelBatchScheduler(_FakeStage(), max_samples_per_step=2)
+    assert sch.get_next_batch_to_run() is None
+    a, b, c, big = _req(1, seed=1), _req(1, h=256, w=256, seed=2), _req(1, seed=3), _req(2, seed=4)
+    for name, r in (("a", a), ("b", b), ("c", c), ("big", big)):
+        sch.add_request(r, identity=name)
+    first = sch.get_next_batch_to_run()
+    assert [i for i, _ in first] == ["a", "c"]                   # b (other shape) keeps its place
+    sch.add_request(_req(1, h=256, w=256, seed=5), identity="late")   # admitted while "running"
+    assert [i for i, _ in sch.get_next_batch_to_run()] == ["b", "late"]
+    assert [i for i, _ in sch.get_next_batch_to_run()] == ["big"]
+    assert sch.get_next_batch_to_run() is None
+    outs = sch.execute(first)
+    assert torch.equal(outs[1], _FakeStage().forward(merge_requests([_req(1, seed=3)])).latents)
 
 
 # ----------------------------------------------------------------------------- schedule --
@@ -250,3 +334,39 @@ def test_gemm_tile_rule_on_the_flux_shapes():
     assert not _big_tile_rule(5, 64, True, cus)
     # exactly full rounds of big tiles beat anything
     assert _big_tile_rule(256 * 16, 256 * 16, True, cus)
+
+
+# ------------------------------------------------------------------- bench.py's launcher --
+def _bench(*argv, env_extra=None):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env,
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_bench_starts_its_own_rank_processes():
+    """`python bench.py --gpus N` must start N rank processes itself (no external launcher):
+    they rendezvous on 127.0.0.1, see RANK / WORLD_SIZE, and rank 0 prints the one JSON line."""
+    import json
+
+    r = _bench("--gpus", "3", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]   # gloo chats on stdout too
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == {"launch_check": True, "n_gpus": 3, "rank_sum": 0 + 1 + 2, "local_rank": 0}
+    # under an external launcher (WORLD_SIZE set) the process is a rank and starts nothing
+    r = _bench("--gpus", "1", "--launch-check", env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    r = _bench("--gpus", "2", "--launch-check", "--launch-check-fail-rank", "1")
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert "rank 1 exited with 3" in r.stderr
