@@ -41,7 +41,8 @@ const char* mi355_last_error(void);
  * 4: mi355_flash_attn_fwd_ex was added; mi355_qk_norm_rope accepts q == NULL.
  * 5: mi355_cfg_normalize and mi355_guidance_rescale were added.
  * 6: mi355_scale_residual_layernorm_modulate, mi355_layernorm_affine and mi355_token_mean were
- *    added. */
+ *    added.
+ * 7: mi355_f16_range_status was added (every bf16 -> half conversion is range-checked). */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -150,8 +151,9 @@ typedef struct {
   /* output columns [f16_begin, f16_end) are stored as IEEE half instead of bf16: the value is
    * first rounded to bf16 (the linear's result, as always) and that bf16 is then written in
    * half format, which is exact for 2^-14 <= |y| <= 65504 (larger saturates, smaller goes
-   * subnormal).  Used for the V third of a fused q|k|v projection that feeds
-   * mi355_flash_attn_fwd_f16v.  Both multiples of 32; begin == end disables. */
+   * subnormal).  Values outside that range never pass silently: see mi355_f16_range_status.
+   * Used for the V third of a fused q|k|v projection that feeds mi355_flash_attn_fwd_f16v.
+   * Both multiples of 32; begin == end disables. */
   int64_t f16_begin, f16_end;
   /* block_scale != 0 (with fp8 != 0): the arithmetic of mi355_fp8_blockwise_scaled_mm instead
    * of per-token x per-channel scales -- sa is [M, K/128] (strides sa_sm, sa_sk; rows indexed
@@ -193,9 +195,30 @@ int mi355_flash_attn_fwd_f16v(const void* q, const void* k, const void* v, void*
                               int64_t o_sh, float softmax_scale, int causal, void* stream);
 
 /* y[r][c] = half(x[r][c]) for a bf16 matrix with row strides ldx / ldy (elements);
- * cols % 8 == 0.  Exact inside half's normal range, saturating at +-65504. */
+ * cols % 8 == 0.  Exact inside half's normal range, saturating at +-65504 (counted, see
+ * mi355_f16_range_status). */
 int mi355_bf16_to_f16(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx,
                       int64_t ldy, void* stream);
+
+/* The value bound of the half-format V operand, and how it is enforced.  No counterpart in the
+ * reference (its attention backends keep V in bf16); it exists because the P.V product here
+ * runs in half to reach the reference's eager result within 1e-3.
+ * Half holds every bf16 value with 2^-14 <= |v| <= 65504 exactly.  Each conversion (the half
+ * columns of mi355_linear_ex, mi355_bf16_to_f16) looks at the largest magnitude of every block
+ * it converts (32 rows x 32 channels in the GEMM epilogue, 512 consecutive values in
+ * mi355_bf16_to_f16) and counts, per device,
+ *   overflow_blocks: blocks holding a value beyond +-65504 (stored saturated: WRONG results);
+ *   tiny_blocks:     blocks whose largest magnitude is nonzero but below 2^-13, i.e. that lie
+ *                    entirely in half's subnormal range and lose relative precision (single
+ *                    small values among normal ones are harmless: their absolute error is
+ *                    below 2^-25).
+ * This call copies the current device's two counters to the host after the work queued on
+ * `stream` has finished (it SYNCHRONISES the stream; do not call it under graph capture) and
+ * zeroes them when reset != 0.  With both output pointers NULL and reset != 0 it only queues
+ * the zeroing on `stream` and does not synchronise.  A caller that sees a non-zero count must redo the work with
+ * bf16 V (f16_begin == f16_end, mi355_flash_attn_fwd): the denoise stage does exactly that. */
+int mi355_f16_range_status(int64_t* overflow_blocks, int64_t* tiny_blocks, int reset,
+                           void* stream);
 
 /* ------------------------------------------------------- norms and rope --
  * rmsnorm(Tensor! output, Tensor input, Tensor weight, float eps, bool pdl)

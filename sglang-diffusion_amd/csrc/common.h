@@ -56,8 +56,30 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
   return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
 }
 
+// Device pointer (for the current device) of the two counters that record bf16 -> half
+// conversions outside half's range: [0] blocks holding a value beyond +-65504 (stored
+// saturated), [1] blocks whose largest magnitude is nonzero but below HALF_TINY_BLOCK, i.e.
+// blocks that live entirely in half's subnormal range and lose relative precision.  Defined in
+// elementwise.hip; returns nullptr (and sets the error string) when the symbol cannot be taken.
+unsigned long long* mi355_f16_range_counters();
+
+// 2^-13: with the largest value of a block at or above this, the subnormal spacing 2^-24 is
+// below 2^-11 of it -- half's own mantissa resolution
+#define HALF_TINY_BLOCK 1.220703125e-4f
+#define HALF_MAX 65504.f
+
+// Record one block's largest |value| (already reduced over the wave) in the range counters.
+__device__ __forceinline__ void note_f16_block(unsigned long long* counters, float block_amax,
+                                               int lane) {
+  if (lane == 0) {
+    if (block_amax > HALF_MAX) atomicAdd(counters, 1ull);
+    else if (block_amax > 0.f && block_amax < HALF_TINY_BLOCK) atomicAdd(counters + 1, 1ull);
+  }
+}
+
 // two floats -> bf16 (round to nearest even, the linear's result) -> the same values in IEEE
-// half, packed lo | hi << 16.  Exact for bf16 values inside half's normal range.
+// half, packed lo | hi << 16.  Exact for bf16 values inside half's normal range; callers feed
+// note_f16_block so that values outside it never pass silently.
 __device__ __forceinline__ unsigned int pack_bf2_as_f16(float lo, float hi) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   const float a = fminf(fmaxf(rbf(lo), -65504.f), 65504.f);

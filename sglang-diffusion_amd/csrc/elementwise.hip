@@ -5,6 +5,8 @@
 // of one) per row with the row held in registers, fp32 math, and every bf16
 // rounding that the eager PyTorch sequence performs reproduced in registers so
 // results match op-by-op execution.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -1105,21 +1107,55 @@ extern "C" int mi355_guidance_rescale(void* noise, const void* cond, float guida
 }
 
 // ---- bf16 -> half (V operand of the half-precision P.V attention) --------------------
+// Range counters of every bf16 -> half conversion the library does (this kernel and the
+// half-format output columns of the GEMM): one copy per device, reached from host code through
+// its per-device address.
+static __device__ unsigned long long f16_range_counters[2];
+
+unsigned long long* mi355_f16_range_counters() {
+  static std::atomic<unsigned long long*> ptr_of[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<unsigned long long*>& slot = ptr_of[dev & 63];
+  unsigned long long* p = slot.load(std::memory_order_acquire);
+  if (!p) {
+    hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(f16_range_counters));
+    if (e != hipSuccess || !p) {
+      mi355_set_error("f16 range counters: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+      return nullptr;
+    }
+    slot.store(p, std::memory_order_release);
+  }
+  return p;
+}
+
 namespace {
 __global__ __launch_bounds__(256) void bf16_to_f16_kernel(const unsigned short* __restrict__ x,
                                                            unsigned short* __restrict__ y,
                                                            int64_t rows, int cols8, int64_t ldx,
-                                                           int64_t ldy) {
+                                                           int64_t ldy,
+                                                           unsigned long long* counters) {
   const int64_t total = rows * cols8;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / cols8;
-    const int c = (int)(i - r * cols8) * 8;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ldx + c);
-    u32x4 o;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  // every wave runs the same number of rounds (inactive lanes contribute 0 to the block max)
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < total; i0 += stride) {
+    const int64_t i = i0 + threadIdx.x;
+    float amax = 0.f;
+    if (i < total) {
+      const int64_t r = i / cols8;
+      const int c = (int)(i - r * cols8) * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ldx + c);
+      u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      o[e] = pack_bf2_as_f16(__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u));
-    *reinterpret_cast<u32x4*>(y + r * ldy + c) = o;
+      for (int e = 0; e < 4; ++e) {
+        const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+        o[e] = pack_bf2_as_f16(lo, hi);
+        amax = fmaxf(amax, fmaxf(fabsf(lo), fabsf(hi)));
+      }
+      *reinterpret_cast<u32x4*>(y + r * ldy + c) = o;
+    }
+    // a block here is the 512 consecutive values one wave converts
+    note_f16_block(counters, group_max<64>(amax), threadIdx.x & 63);
   }
 }
 }  // namespace
@@ -1133,11 +1169,42 @@ extern "C" int mi355_bf16_to_f16(const void* x, void* y, int64_t rows, int64_t c
                     ((uintptr_t)y % 16) == 0,
                 "bf16_to_f16: cols and strides must be multiples of 8, pointers 16-byte aligned");
   MI355_REQUIRE(cols / 8 < (1ll << 31), "bf16_to_f16: row too long");
+  unsigned long long* counters = mi355_f16_range_counters();
+  if (!counters) return MI355_EHIP;
   const int64_t total = rows * (cols / 8);
   const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   hipLaunchKernelGGL(bf16_to_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)x, (unsigned short*)y, rows, (int)(cols / 8), ldx, ldy);
+                     (const unsigned short*)x, (unsigned short*)y, rows, (int)(cols / 8), ldx, ldy,
+                     counters);
   MI355_CHECK_LAUNCH("bf16_to_f16");
+  return MI355_OK;
+}
+
+extern "C" int mi355_f16_range_status(int64_t* overflow_blocks, int64_t* tiny_blocks, int reset,
+                                      void* stream) {
+  MI355_REQUIRE((overflow_blocks && tiny_blocks) || (!overflow_blocks && !tiny_blocks && reset),
+                "f16_range_status: give both outputs, or neither with reset != 0");
+  unsigned long long* counters = mi355_f16_range_counters();
+  if (!counters) return MI355_EHIP;
+  hipStream_t st = (hipStream_t)stream;
+  if (!overflow_blocks) {  // reset only: queued on the stream, no synchronisation
+    hipError_t e0 = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st);
+    if (e0 != hipSuccess) {
+      mi355_set_error("f16_range_status: %s", hipGetErrorString(e0));
+      return MI355_EHIP;
+    }
+    return MI355_OK;
+  }
+  unsigned long long host[2] = {0, 0};
+  hipError_t e = hipMemcpyAsync(host, counters, sizeof(host), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && reset) e = hipMemsetAsync(counters, 0, sizeof(host), st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    mi355_set_error("f16_range_status: %s", hipGetErrorString(e));
+    return MI355_EHIP;
+  }
+  *overflow_blocks = (int64_t)host[0];
+  *tiny_blocks = (int64_t)host[1];
   return MI355_OK;
 }
 

@@ -41,6 +41,7 @@ struct GemmParams {
   mi355_rowmap a_map, o_map;
   int act;
   int f16_begin, f16_end;  // output columns stored as half
+  unsigned long long* f16_counters;  // range counters of those columns (see common.h)
   // block-scaled variant
   int64_t sa_sm, sa_sk, sb_sk, sb_sn;
   int group;  // M tiles per XCD chunk of the tile walk
@@ -82,6 +83,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         const int nblk = n0 + wn * TN * 32 + i * 32;
         const bool as_f16 = nblk >= p.f16_begin && nblk < p.f16_end;
         unsigned int pk[4][2];
+        float amax = 0.f;  // largest |value| of this 32-row x 32-channel block (half columns)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           // per-channel scale and bias of this lane's run of 4 channels
@@ -107,11 +109,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           if (as_f16) {
             pk[g][0] = pack_bf2_as_f16(y[0], y[1]);
             pk[g][1] = pack_bf2_as_f16(y[2], y[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(y[e]));
           } else {
             pk[g][0] = pack_bf2(y[0], y[1]);
             pk[g][1] = pack_bf2(y[2], y[3]);
           }
         }
+        if (as_f16) note_f16_block(p.f16_counters, group_max<64>(amax), lane);
         // widen: lanes l and l+32 exchange so each owns 8 consecutive channels
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
@@ -707,6 +712,11 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
   p.act = a->act;
   p.f16_begin = (int)a->f16_begin;
   p.f16_end = (int)a->f16_end;
+  p.f16_counters = nullptr;
+  if (p.f16_end > p.f16_begin) {
+    p.f16_counters = mi355_f16_range_counters();
+    if (!p.f16_counters) return MI355_EHIP;
+  }
   p.sa_sm = p.sa_sk = p.sb_sk = p.sb_sn = 0;
   if (a->block_scale) {
     p.sa_sm = a->sa_sm;

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mi355_flash_attn_fwd": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
     "mi355_flash_attn_fwd_f16v": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
     "mi355_bf16_to_f16": (_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
+    "mi355_f16_range_status": (_int, [ctypes.POINTER(_i64), ctypes.POINTER(_i64), _int, _ptr]),
     "mi355_rmsnorm": (_int, [_ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _i64, _f32, _ptr]),
     "mi355_fused_add_rmsnorm": (_int, [_ptr, _ptr, _ptr, _int, _i64, _i64, _f32, _ptr]),
     "mi355_qk_norm_rope": (
@@ -142,7 +143,7 @@ _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def load_library() -> ctypes.CDLL:
@@ -378,9 +379,40 @@ def value_to_f16(v: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# Process-wide switch of the V operand's format.  True: V is converted to IEEE half and the
+# P.V product runs in half (closest to the fp32-softmax result).  False: V stays bf16 and the
+# probabilities are rounded to bf16 (the form every flash kernel the reference calls uses).
+# The denoise stage clears it when a conversion left half's range (f16_range_status).
+VALUE_HALF = True
+
+
+def f16_range_status(device=None, reset: bool = True):
+    """(overflow_blocks, tiny_blocks) of the bf16 -> half conversions done on `device` since the
+    last reset; waits for the device's current stream."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    over, tiny = _i64(0), _i64(0)
+    with torch.cuda.device(dev):
+        _check(load_library().mi355_f16_range_status(
+            ctypes.byref(over), ctypes.byref(tiny), int(bool(reset)),
+            torch.cuda.current_stream(dev).cuda_stream), "f16_range_status")
+    return int(over.value), int(tiny.value)
+
+
+def f16_range_reset(device=None) -> None:
+    """Zero the device's range counters (queued on its current stream, no synchronisation)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        _check(load_library().mi355_f16_range_status(
+            None, None, 1, torch.cuda.current_stream(dev).cuda_stream), "f16_range_status")
+
+
 def attention(q, k, v, out, lse, softmax_scale: float) -> None:
-    """Dense attention on bf16 q, k, v with the half-precision P.V product."""
-    flash_attn_fwd(q, k, value_to_f16(v), out, lse, softmax_scale, False, v_is_f16=True)
+    """Dense attention on bf16 q, k, v: half-precision P.V product while VALUE_HALF holds,
+    else the bf16 form."""
+    if VALUE_HALF:
+        flash_attn_fwd(q, k, value_to_f16(v), out, lse, softmax_scale, False, v_is_f16=True)
+    else:
+        flash_attn_fwd(q, k, v, out, lse, softmax_scale, False, v_is_f16=False)
 
 
 # --------------------------------------------------------------- norm / rope --

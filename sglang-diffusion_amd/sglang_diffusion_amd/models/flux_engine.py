@@ -258,7 +258,12 @@ class FluxEngine:
 
     # --------------------------------------------------------------------------- step --
     def step(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance,
-             freqs_cis) -> torch.Tensor:
+             freqs_cis, probe=None) -> torch.Tensor:
+        """`probe` (tests only): an object whose optional methods see the run from inside --
+        `temb(t) -> t` may replace the conditioning vector, `before(kind, i, joint)` /
+        `after(kind, i, joint)` are called around block i of kind "d" (double) / "s" (single)
+        with the joint hidden state viewed as [B, S_txt + S_img, D] and may overwrite or copy
+        it.  That is how a single block is compared with the CPU oracle on identical inputs."""
         m = self.model
         D, H, dh = self.D, self.H, self.dh
         B, Ti, Cin = hidden_states.shape
@@ -278,6 +283,8 @@ class FluxEngine:
             temb = m.time_text_embed(timestep, guidance, pooled_projections)
         else:
             temb = m.time_text_embed(timestep, pooled_projections)
+        if probe is not None and hasattr(probe, "temb"):
+            temb = probe.temb(temb)
         _C.activation(ws["silu_temb"], temb.contiguous(), 0)
         self._run("modulation", 2.0 * B * self.n_mod * D, 2.0 * self.n_mod * D, _C.linear_bf16,
                   ws["silu_temb"], self.mod_w, self.mod_b, mod, 0)
@@ -298,8 +305,10 @@ class FluxEngine:
         attn4 = attn.view(B, S, H, dh)
         scale = dh ** -0.5
         # the V third of every fused q|k|v projection is written in half format: the attention
-        # kernel multiplies half probabilities with half values
-        vcols = (2 * D, 3 * D)
+        # kernel multiplies half probabilities with half values (bf16 V and bf16 probabilities
+        # once a value left half's range, see _C.VALUE_HALF)
+        v_half = bool(_C.VALUE_HALF)
+        vcols = (2 * D, 3 * D) if v_half else None
 
         if self.block:
             def quant(x, q, s_):  # per (token, 128 channels), fp8.py:303-352 on a block checkpoint
@@ -322,7 +331,8 @@ class FluxEngine:
         # The text rows of a double block depend on the image rows only through the joint
         # attention, so their chain can run on a second stream beside the image chain.
         main = torch.cuda.current_stream(dev)
-        side = self._side(dev) if (self.overlap_text and self.trace is None and self.dbl) else None
+        side = (self._side(dev) if (self.overlap_text and self.trace is None and probe is None
+                                    and self.dbl) else None)
         if side is not None:
             side.wait_event(main.record_event())
 
@@ -330,7 +340,15 @@ class FluxEngine:
             return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
 
         # ------------------------------------------------------------------ double blocks --
+        joint3 = joint.view(B, S, D)
+
+        def tell(when, kind, i):
+            fn = getattr(probe, when, None) if probe is not None else None
+            if fn is not None:
+                fn(kind, i, joint3)
+
         for i, blk in enumerate(self.dbl):
+            tell("before", "d", i)
             oi, ot = self.mod_off[("d", i, "img")], self.mod_off[("d", i, "txt")]
             a, sa = norm_in(blk["qkv"].fp8, chunk(oi, 0), chunk(oi, 1), Ti, map_i, Mi)
             self._lin(blk["qkv"], a, qkv, M=Mi, sa=sa, o_map=map_i, f16_cols=vcols)
@@ -343,7 +361,7 @@ class FluxEngine:
             self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["naq"],
                       blk["nak"], blk["nq"], blk["nk"], Tt, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
-                      attn4, None, scale, False, True,
+                      attn4, None, scale, False, v_half,
                       q_norm=(blk["naq"], blk["nq"], Tt, blk["eps"]), q_rope=(cos, sin))
             if blk["to_out"].fp8:
                 self._run("elementwise", 0.0, 3.0 * Ms * D, quant, attn, ws["aq"], ws["as_"])
@@ -367,6 +385,7 @@ class FluxEngine:
                     self._lin_mod(f1, xn[:M], ffh, M=M, act=1)
                     self._lin_mod(f2, ffh, joint, M=M, o_map=rmap, residual=joint,
                                   gate=chunk(off, 5), gate_rows=T)
+            tell("after", "d", i)
         if side is not None:
             main.wait_event(side.record_event())
 
@@ -376,6 +395,7 @@ class FluxEngine:
         attn_in_cat = cat.view(B, S, catw)[:, :, :D].unflatten(-1, (H, dh))
         mlp_cols = cat[:, D:]
         for i, blk in enumerate(self.sgl):
+            tell("before", "s", i)
             off = self.mod_off[("s", i)]
             a, sa = norm_in(blk["qkv"].fp8, chunk(off, 0), chunk(off, 1), S, None, Ms)
             self._lin(blk["qkv"], a, qkv, M=Ms, sa=sa, f16_cols=vcols)
@@ -383,7 +403,7 @@ class FluxEngine:
             self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["nq"],
                       blk["nk"], blk["nq"], blk["nk"], 0, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
-                      attn_in_cat, None, scale, False, True,
+                      attn_in_cat, None, scale, False, v_half,
                       q_norm=(blk["nq"], blk["nq"], 0, blk["eps"]), q_rope=(cos, sin))
             if blk["out"].fp8:
                 self._run("elementwise", 0.0, 3.0 * Ms * catw, quant, cat, ws["cq"], ws["cs"])
@@ -392,6 +412,7 @@ class FluxEngine:
                 c_src, c_s = cat, None
             self._lin(blk["out"], c_src, joint, M=Ms, sa=c_s, residual=joint, gate=chunk(off, 2),
                       gate_rows=S)
+            tell("after", "s", i)
 
         # ---- output head: AdaLayerNormContinuous (scale first) + proj_out on image rows ------
         oo = self.mod_off[("out",)]

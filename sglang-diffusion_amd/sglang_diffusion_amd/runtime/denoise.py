@@ -162,7 +162,32 @@ class DenoisingStage:
 
     @torch.no_grad()
     def forward(self, batch: Req, num_steps: Optional[int] = None) -> Req:
-        """Runs the loop in place on `batch.latents`; `num_steps` truncates it (benchmarks)."""
+        """Runs the loop in place on `batch.latents`; `num_steps` truncates it (benchmarks).
+
+        The attention kernels take V in IEEE half (exact for 2^-14 <= |v| <= 65504).  Every
+        conversion is range-checked on the device; the counters are read once here, after the
+        loop, and if a value left the range the whole loop is run again from the initial
+        latents with bf16 V (and stays that way for the process): wrong values never leave
+        this call, and the common case pays one 16-byte copy per request batch."""
+        first = batch.latents
+        check = _C.VALUE_HALF and first.is_cuda and not torch.cuda.is_current_stream_capturing()
+        if check:
+            _C.f16_range_reset(first.device)   # counts of earlier, unrelated work do not matter
+        out = self._loop(batch, num_steps)
+        if check:
+            over, tiny = _C.f16_range_status(first.device, reset=True)
+            if over or tiny:
+                import warnings
+
+                warnings.warn(f"attention V left IEEE half's range in this request batch ({over} "
+                              f"blocks beyond 65504, {tiny} blocks entirely below 2^-13): "
+                              "re-running it with bf16 V, which stays on for this process")
+                _C.VALUE_HALF = False
+                batch.latents = first
+                out = self._loop(batch, num_steps)
+        return out
+
+    def _loop(self, batch: Req, num_steps: Optional[int] = None) -> Req:
         device = batch.latents.device
         timesteps = self.prepare_timesteps(batch, device)
         bsz = batch.batch_size
