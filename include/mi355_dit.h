@@ -205,7 +205,7 @@ int mi355_bf16_to_f16(const void* x, void* y, int64_t rows, int64_t cols, int64_
  * runs in half to reach the reference's eager result within 1e-3.
  * Half holds every bf16 value with 2^-14 <= |v| <= 65504 exactly.  Each conversion (the half
  * columns of mi355_linear_ex, mi355_bf16_to_f16) looks at the largest magnitude of every block
- * it converts (32 rows x 32 channels in the GEMM epilogue, 512 consecutive values in
+ * it converts (32 rows x 32 channels in the GEMM epilogue, 128 consecutive values in
  * mi355_bf16_to_f16) and counts, per device,
  *   overflow_blocks: blocks holding a value beyond +-65504 (stored saturated: WRONG results);
  *   tiny_blocks:     blocks whose largest magnitude is nonzero but below 2^-13, i.e. that lie

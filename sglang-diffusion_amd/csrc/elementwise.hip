@@ -1154,8 +1154,9 @@ __global__ __launch_bounds__(256) void bf16_to_f16_kernel(const unsigned short* 
       }
       *reinterpret_cast<u32x4*>(y + r * ldy + c) = o;
     }
-    // a block here is the 512 consecutive values one wave converts
-    note_f16_block(counters, group_max<64>(amax), threadIdx.x & 63);
+    // a block here is the 128 consecutive values (one attention head's row when rows are
+    // [heads x 128]) that 16 neighbouring lanes convert
+    note_f16_block(counters, group_max<16>(amax), threadIdx.x & 15);
   }
 }
 }  // namespace

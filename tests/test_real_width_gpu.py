@@ -28,13 +28,19 @@ S = TT + TI
 # now and then (each flip is 2^-8 relative on that element), and (b) the attention kernel's
 # probabilities rounded to 16 bits before P.V against the oracle's fp32 softmax.  The budget
 # test below measures each operator alone at this size; the bars here are those figures
-# composed: bf16 blocks stay under 2e-3, single blocks (one GEMM after the attention instead of
-# three, and a 5x wider contraction that averages flips out) under 1e-3.
-BAR = {("d", False): 2e-3, ("s", False): 1e-3,
-       # W8A8: the input of every quantised linear is re-rounded to e4m3 (3 mantissa bits).  A
-       # one-ulp bf16 difference in an activation moves its fp8 code with probability ~1/16 and
-       # then costs 2^-4 relative on that element: expected excess ~ sqrt(1/16 * p_flip) * 2^-4.
-       ("d", True): 6e-3, ("s", True): 4e-3}
+# composed.  Measured on MI355X: bf16 double block 1.7e-3 on either stream, single block
+# 3.5e-4; W8A8 2.2e-3 and 1.2e-3.
+#   double, bf16 <= 2e-3: the attention output differs by 8.6e-4 (operator budget below); it
+#     passes through to_out (linear: same relative size), is added to the residual, and the
+#     sum feeds LayerNorm -> FF1 -> GELU -> FF2, whose output is rounded to bf16 three more
+#     times on slightly different operands: the feed-forward branch roughly doubles what the
+#     attention branch brought in.  No other operator contributes above 5e-5.
+#   single, bf16 <= 1e-3 (measured 3.5e-4): attention output and GELU(proj_mlp) are
+#     concatenated and contracted ONCE over K = 15360; there is no second branch behind it.
+#   W8A8 <= 3e-3 / 2e-3: the input of every quantised linear is re-rounded to e4m3 (3 mantissa
+#     bits); a one-ulp bf16 difference upstream moves an fp8 code now and then and costs 2^-4
+#     relative on that element (qkv GEMM alone: 2.5e-4 against 4e-5 in bf16).
+BAR = {("d", False): 2e-3, ("s", False): 1e-3, ("d", True): 3e-3, ("s", True): 2e-3}
 
 
 def _real_width(device, fp8):
@@ -146,11 +152,13 @@ def test_modulation_gemm_at_real_width(device):
 
 # ---- operator budget of the double block's image stream, each operator on the oracle's input --
 OP_BAR = {
-    # bf16 in, bf16 out, fp32 inside; only summation order differs -> rare one-ulp flips
-    "layernorm_modulate": 1e-3, "qkv_gemm": 1e-3, "qk_norm_rope": 1e-3,
-    # 16-bit probabilities before P.V (half here, bf16 in every flash kernel the reference calls)
+    # bf16 in, bf16 out, fp32 inside; only the summation order differs -> rare one-ulp flips
+    # (measured 5e-6 .. 5e-5; W8A8 q|k|v 2.5e-4)
+    "layernorm_modulate": 1e-4, "qkv_gemm": 5e-4, "qk_norm_rope": 1e-4,
+    # 16-bit probabilities before P.V (half here, bf16 in every flash kernel the reference
+    # calls); measured 8.6e-4: this operator carries the block's deviation
     "attention": 1e-3,
-    "to_out_gate_residual": 1e-3, "ff1_gelu": 1e-3, "ff2_gate_residual": 1e-3,
+    "to_out_gate_residual": 1e-4, "ff1_gelu": 1e-4, "ff2_gate_residual": 1e-4,
 }
 
 
