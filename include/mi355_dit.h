@@ -42,7 +42,8 @@ const char* mi355_last_error(void);
  * 5: mi355_cfg_normalize and mi355_guidance_rescale were added.
  * 6: mi355_scale_residual_layernorm_modulate, mi355_layernorm_affine and mi355_token_mean were
  *    added.
- * 7: mi355_f16_range_status was added (every bf16 -> half conversion is range-checked). */
+ * 7: mi355_f16_range_status was added (every bf16 -> half conversion is range-checked).
+ * 8: mi355_guidance_rescale_static was added. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -360,6 +361,20 @@ int mi355_cfg_normalize(void* noise, const void* cond, float factor, int64_t n, 
                         void* stream);
 int mi355_guidance_rescale(void* noise, const void* cond, float guidance_rescale, int64_t batch,
                            int64_t per_sample, float* scratch, void* stream);
+
+/* mi355_guidance_rescale without the scratch argument.  No counterpart in the reference: it is
+ * for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  The per-sample partial moments live in a
+ * 64-KiB array that is part of the library's device image (every GPU the library runs on
+ * holds one copy until the process ends); the call itself allocates and frees nothing.
+ * Same arithmetic, same results as mi355_guidance_rescale.  batch <= 64
+ * (MI355_STATIC_RESCALE_MAX_BATCH), larger batches are rejected with MI355_EINVAL.  All calls
+ * on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams) race;
+ * calls on one stream, or otherwise ordered, are safe, and nothing needs clearing between
+ * them. */
+#define MI355_STATIC_RESCALE_MAX_BATCH 64
+int mi355_guidance_rescale_static(void* noise, const void* cond, float guidance_rescale,
+                                  int64_t batch, int64_t per_sample, void* stream);
 
 /* Every option of the attention kernel in one argument block; the two entry points above are
  * this call with v_is_f16 = 0 / 1 and no query transform.

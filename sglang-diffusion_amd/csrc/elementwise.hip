@@ -1106,6 +1106,50 @@ extern "C" int mi355_guidance_rescale(void* noise, const void* cond, float guida
   return MI355_OK;
 }
 
+// ---- guidance_rescale for callers that cannot allocate --------------------------------
+// Same kernels as mi355_guidance_rescale; the per-sample partial moments go to a file-scope
+// device array instead of a caller-provided buffer.  Each GPU holds its own copy of the array
+// at its own address, taken once per device with hipGetSymbolAddress; host code uses that
+// address (never the array's name) wherever it needs the memory.
+static __device__ __align__(256) float scratch[MI355_STATIC_RESCALE_MAX_BATCH * 64 * 4];
+static_assert(sizeof(float) * MI355_STATIC_RESCALE_MAX_BATCH * 64 * 4 == 64 * 1024,
+              "64 KiB of device memory per GPU");
+
+static float* static_scratch_ptr() {
+  static_assert(CFG_MOMENT_BLOCKS == 64, "scratch holds 64 partial quadruples per sample");
+  static std::atomic<float*> ptr_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    mi355_set_error("guidance_rescale_static: cannot identify the current device");
+    return nullptr;
+  }
+  std::atomic<float*>& slot = ptr_of[dev];
+  float* ptr = slot.load(std::memory_order_acquire);
+  if (!ptr) {
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+      mi355_set_error("guidance_rescale_static: hipGetSymbolAddress failed: %s",
+                      hipGetErrorString(e));
+      return nullptr;
+    }
+    slot.store(ptr, std::memory_order_release);
+  }
+  return ptr;
+}
+
+extern "C" int mi355_guidance_rescale_static(void* noise, const void* cond, float guidance_rescale,
+                                             int64_t batch, int64_t per_sample, void* stream) {
+  MI355_REQUIRE(batch >= 0 && batch <= MI355_STATIC_RESCALE_MAX_BATCH,
+                "guidance_rescale_static: batch %ld exceeds the built-in scratch (at most %d "
+                "samples per call; use mi355_guidance_rescale with a caller buffer beyond that)",
+                (long)batch, MI355_STATIC_RESCALE_MAX_BATCH);
+  float* ptr = static_scratch_ptr();
+  if (!ptr) return MI355_EHIP;
+  // every partial the apply kernel reads is written by this call's moments kernel first, so
+  // what an earlier (larger) call left in the array never matters
+  return mi355_guidance_rescale(noise, cond, guidance_rescale, batch, per_sample, ptr, stream);
+}
+
 // ---- bf16 -> half (V operand of the half-precision P.V attention) --------------------
 // Range counters of every bf16 -> half conversion the library does (this kernel and the
 // half-format output columns of the GEMM): one copy per device, reached from host code through

@@ -137,13 +137,14 @@ SIGNATURES = {
     "mi355_cfg_combine": (_int, [_ptr, _ptr, _ptr, _f32, _i64, _ptr]),
     "mi355_cfg_normalize": (_int, [_ptr, _ptr, _f32, _i64, _ptr, _ptr]),
     "mi355_guidance_rescale": (_int, [_ptr, _ptr, _f32, _i64, _i64, _ptr, _ptr]),
+    "mi355_guidance_rescale_static": (_int, [_ptr, _ptr, _f32, _i64, _i64, _ptr]),
 }
 
 _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def load_library() -> ctypes.CDLL:
@@ -650,3 +651,19 @@ def guidance_rescale(noise, cond, rescale: float, scratch=None) -> None:
         ),
         "guidance_rescale",
     )
+
+
+def guidance_rescale_static(noise, cond, rescale: float) -> None:
+    """guidance_rescale through the entry point that allocates nothing (the library's own
+    64-KiB scratch; at most 64 samples per call)."""
+    if not (noise.is_contiguous() and cond.is_contiguous()) or noise.shape != cond.shape:
+        raise RuntimeError("guidance_rescale: contiguous tensors of one shape expected")
+    B = noise.shape[0]
+    with torch.cuda.device(noise.device):
+        _check(
+            load_library().mi355_guidance_rescale_static(
+                noise.data_ptr(), cond.data_ptr(), float(rescale), B, noise.numel() // max(B, 1),
+                _stream(noise),
+            ),
+            "guidance_rescale_static",
+        )
