@@ -43,7 +43,9 @@ const char* mi355_last_error(void);
  * 6: mi355_scale_residual_layernorm_modulate, mi355_layernorm_affine and mi355_token_mean were
  *    added.
  * 7: mi355_f16_range_status was added (every bf16 -> half conversion is range-checked).
- * 8: mi355_guidance_rescale_static was added. */
+ * 8: mi355_guidance_rescale_static was added.
+ * 9: mi355_linear_args gained w_shuffled; mi355_linear_grouped, mi355_shuffle_weight and
+ *    mi355_shuffled_weight_bytes were added. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -163,8 +165,35 @@ typedef struct {
    * that (activation, gate/residual, row maps, half columns) works as in the other modes. */
   int block_scale;
   int64_t sa_sm, sa_sk, sb_sk, sb_sn;
+  /* Optional: the same weight in MFMA-fragment order (mi355_shuffle_weight), or NULL.  With it
+   * (and N % 32 == 0, no block scales, a shape that takes 256 x 256 tiles) the weight operand
+   * CAN be loaded from global memory straight into registers, only the activations passing
+   * through LDS; results are bit-identical to the NULL case.  Measured 4-9 % slower than the
+   * LDS-staged weight on every Flux shape, so the path is taken only when the environment
+   * variable MI355_GEMM_WDIRECT is set (A/B timing); otherwise the field is ignored. */
+  const void* w_shuffled;
 } mi355_linear_args;
 int mi355_linear_ex(const mi355_linear_args* args, void* stream);
+
+/* One or two mi355_linear_ex problems submitted together: the reference runs the text-stream
+ * and the image-stream projections of a double block as separate linears
+ * (models/dits/flux.py:182-205,401-413, mlp.py:94-113).  Each problem computes exactly what
+ * mi355_linear_ex computes for it.  The pair shares ONE launch (a persistent grid walking the
+ * output tiles of both) only on the register-fed weight kernel (both w_shuffled given, one
+ * dtype, MI355_GEMM_WDIRECT set); otherwise the problems are launched one after the other,
+ * which measured as fast: the image-stream problem fills whole rounds of the grid by itself. */
+int mi355_linear_grouped(const mi355_linear_args* args, int count, void* stream);
+
+/* Weight pre-shuffle for the register-fed weight path.  No counterpart in the reference (its
+ * checkpoints keep [N, K] row-major weights, tools/convert_hf_to_fp8.py:48-79 and
+ * layers/quantization/fp8.py:303-352; this runs once after loading and leaves the checkpoint
+ * format alone).  out receives w[N, K] (row stride ldw elements; fp8 or bf16) as
+ * [N/32][k-steps][fragment]: the 32-row x 64-byte (fp8) or 32-row x 16-element (bf16) A operand
+ * of one MFMA, 16 bytes per lane, lanes in order.  N % 32 == 0, K bytes % 128 == 0;
+ * mi355_shuffled_weight_bytes gives out's size (-1 for shapes that cannot be shuffled). */
+int64_t mi355_shuffled_weight_bytes(int64_t N, int64_t K, int fp8);
+int mi355_shuffle_weight(const void* w, void* out, int64_t N, int64_t K, int64_t ldw, int fp8,
+                         void* stream);
 
 /* ------------------------------------------------------------ attention --
  * Dense non-causal (or causal) softmax(Q K^T * scale) V, bf16 in/out, fp32

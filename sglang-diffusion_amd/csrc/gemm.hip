@@ -19,7 +19,11 @@
 // 32x32 accumulator has the token (m) on the lane and 4-element runs of n in
 // registers: after one permlane32_swap per register pair every lane owns 8
 // consecutive output channels of one token and stores 16 bytes.
+#include <stdlib.h>
+
+#include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "common.h"
 
@@ -45,6 +49,16 @@ struct GemmParams {
   // block-scaled variant
   int64_t sa_sm, sa_sk, sb_sk, sb_sn;
   int group;  // M tiles per XCD chunk of the tile walk
+  // weight in MFMA-fragment order (mi355_shuffle_weight) and its k-steps per 32-row block
+  const unsigned char* wsh;
+  int wsh_ksteps;
+};
+
+// Up to two problems of one dtype walked by ONE persistent grid: the text-stream GEMM of a
+// double block rides in the image-stream launch instead of running alone on a worse tile.
+struct GroupParams {
+  GemmParams pr[2];
+  int nprob;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -477,6 +491,258 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   }
 }
 
+// ---- the weight operand straight from global memory into registers ---------------------
+// Same tile (256 x 256 x 128 B), same MFMAs in the same order (bit-identical results) as
+// gemm_kernel<DT, 4, 2, 2, 4>, but only the ACTIVATION tile goes through LDS.  The weight is
+// static: mi355_shuffle_weight stores it once in fragment order, [N/32][k-steps][64 lanes x 16 B
+// (x 2 for fp8)], so a wave's A operands of one K tile are two contiguous 4-KiB runs that it
+// loads with 16-byte-per-lane global loads one K tile ahead, into registers, with no barrier
+// in between.  That takes the weight's 32 KiB per K tile out of the LDS-DMA fill and its
+// 128 KiB per K tile out of the LDS reads (with both operands in LDS the LDS port is as busy
+// as the matrix pipe: 64 KiB written + 192 KiB read per 2048 MFMA clocks).  Waves are laid out
+// 2 (M) x 4 (N), 128 x 64 outputs each: a weight fragment is shared by two waves only, the
+// activation fragments (LDS) by four.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void gemm_wdirect_kernel(GroupParams gp) {
+  constexpr int WAVES_M = 2, WAVES_N = 4, TM = 4, TN = 2, NW = 8;
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  constexpr int XSTAGE = BM * 128;
+  constexpr int NPIECE = BM / 8 / NW;  // 1-KiB LDS-DMA pieces per wave per K tile
+  constexpr int KSTEPS = DT == 0 ? 4 : 2;
+  constexpr int FRAG = DT == 0 ? 1024 : 2048;  // bytes of one (32 rows, k-step) fragment
+  constexpr int SCRATCH_WAVE = 32 * 128;
+  constexpr int EPI_OFF = 2 * XSTAGE;
+  constexpr int TABLE_OFF = EPI_OFF + NW * SCRATCH_WAVE;
+  typedef typename std::conditional<DT == 0, bf16x8, i32x8>::type wfrag_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WAVES_M;
+  const int wn = wave / WAVES_M;
+
+  const int nt0 = gp.pr[0].M > 0 ? ((gp.pr[0].M + BM - 1) / BM) * ((gp.pr[0].N + BN - 1) / BN) : 0;
+  const int nt1 = gp.nprob > 1 ? ((gp.pr[1].M + BM - 1) / BM) * ((gp.pr[1].N + BN - 1) / BN) : 0;
+  const int total = nt0 + nt1;
+
+  // Problem parameters are read from the kernel-argument segment where they are needed (tile
+  // boundaries only); nothing but the loop count stays live across the K loop.
+  auto tile_of = [&](const GemmParams& q, int vbl, int& m0, int& n0) {
+    const int tiles_m = (q.M + BM - 1) / BM, tiles_n = (q.N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int qq = nwg >> 3, rr = nwg & 7, xcd = vbl & 7;
+    const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (vbl >> 3);
+    const int GROUP = q.group;
+    const int group_sz = GROUP * tiles_n;
+    const int gidx = bid / group_sz;
+    const int first_m = gidx * GROUP;
+    const int gm = min(tiles_m - first_m, GROUP);
+    const int in_g = bid - gidx * group_sz;
+    m0 = (first_m + in_g % gm) * BM;
+    n0 = (in_g / gm) * BN;
+  };
+
+  // activation rows: wave-uniform base (advances 128 B per K tile) + per-lane 32-bit offsets;
+  // weight fragments: wave-uniform bases (advance KSTEPS * FRAG per K tile) + lane * 16
+  const unsigned char* xbase = nullptr;
+  unsigned int xoff[NPIECE];
+  const unsigned char* wbase[TN];
+  const unsigned int woff = lane * 16;
+  auto set_src = [&](const GemmParams& q, int m0, int n0) {
+    xbase = q.a;
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int piece = wave + i * NW;
+      const int row = piece * 8 + (lane >> 3);
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      int gmrow = m0 + row;
+      if (gmrow >= q.M) gmrow = q.M - 1;
+      xoff[i] = (unsigned int)(map_row32(gmrow, (int)q.a_map.rows_per_batch, q.a_map.batch_rows,
+                                         q.a_map.row_offset) * q.lda_b + lc * 16);
+    }
+    const int nb_max = q.N / 32 - 1;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      int nb = (n0 + wn * TN * 32 + i * 32) >> 5;
+      if (nb > nb_max) nb = nb_max;
+      wbase[i] = q.wsh + (int64_t)nb * q.wsh_ksteps * FRAG;
+    }
+  };
+  auto stage_x = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int piece = wave + i * NW;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xbase + xoff[i]),
+                                       (lds_ptr_t)(smem + buf * XSTAGE + piece * 1024), 16, 0, 0);
+    }
+    xbase += 128;
+  };
+  wfrag_t wf[2][TN][KSTEPS];
+  auto load_w = [&](auto setc) {
+    constexpr int set = decltype(setc)::value;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const unsigned char* wp = wbase[i] + woff;
+#pragma unroll
+      for (int s2 = 0; s2 < KSTEPS; ++s2) {
+        if constexpr (DT == 0) {
+          wf[set][i][s2] = *reinterpret_cast<const bf16x8*>(wp + s2 * FRAG);
+        } else {
+          const i32x4 lo = *reinterpret_cast<const i32x4*>(wp + s2 * FRAG);
+          const i32x4 hi = *reinterpret_cast<const i32x4*>(wp + s2 * FRAG + 1024);
+          wf[set][i][s2] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+      wbase[i] += KSTEPS * FRAG;
+    }
+  };
+
+  float sb_reg = 1.f, sa_reg = 1.f;
+  unsigned short bias_reg = 0;
+  auto load_tables = [&](const GemmParams& q, int m0, int n0) {
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if constexpr (DT == 1) sb_reg = n < q.N ? q.sb[n] : 1.f;
+      bias_reg = (q.bias && n < q.N) ? q.bias[n] : (unsigned short)0;
+    }
+    if constexpr (DT == 1) {
+      if (tid < BM) {
+        const int mc = min(m0 + tid, q.M - 1);
+        sa_reg = q.sa[map_row32(mc, (int)q.a_map.rows_per_batch, q.a_map.batch_rows,
+                                q.a_map.row_offset)];
+      }
+    }
+  };
+
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int swz = (r >> 1) & 7;
+  int coff[KSTEPS];
+#pragma unroll
+  for (int s2 = 0; s2 < KSTEPS; ++s2) {
+    const int c = DT == 0 ? (2 * s2 + h) : (4 * s2 + 2 * h);
+    coff[s2] = ((c ^ swz) << 4);
+  }
+  const int x_row_off = (wm * TM * 32 + r) * 128;
+  const int unit_scale = 0x7f7f7f7f;
+
+  int vb = blockIdx.x;
+  if (vb >= total) return;
+  int m0, n0, ktiles;
+  {
+    const GemmParams& q = gp.pr[vb >= nt0 ? 1 : 0];
+    tile_of(q, vb >= nt0 ? vb - nt0 : vb, m0, n0);
+    set_src(q, m0, n0);
+    load_tables(q, m0, n0);
+    ktiles = q.ktiles;
+  }
+  stage_x(0);
+  load_w(std::integral_constant<int, 0>{});
+
+  while (true) {
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // K tile kt computes from LDS stage SET and weight registers SET (compile time) while the
+    // other stage and register set fill
+    auto ktile = [&](auto setc, int kt) {
+      constexpr int cur = decltype(setc)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < ktiles) {
+        stage_x(cur ^ 1);
+        load_w(std::integral_constant<int, cur ^ 1>{});
+      }
+      const unsigned char* sbase = smem + cur * XSTAGE + x_row_off;
+#pragma unroll
+      for (int s2 = 0; s2 < KSTEPS; ++s2) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          if constexpr (DT == 0) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sbase + j * 32 * 128 + coff[s2]);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i][s2], xf, acc[i][j], 0,
+                                                                   0, 0);
+          } else {
+            const unsigned char* pb = sbase + j * 32 * 128;
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(pb + coff[s2]);
+            const i32x4 hi = *reinterpret_cast<const i32x4*>(pb + (coff[s2] ^ 16));
+            const i32x8 xf = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                  wf[cur][i][s2], xf, acc[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
+          }
+        }
+      }
+    };
+    for (int kt = 0; kt < ktiles; kt += 2) {
+      ktile(std::integral_constant<int, 0>{}, kt);
+      if (kt + 1 < ktiles) ktile(std::integral_constant<int, 1>{}, kt + 1);
+    }
+
+    // ---- tile done: park the tables, start the next tile's first K tile, run the epilogue --
+    __syncthreads();  // every wave is done reading the activation stages
+    float* sb_l = reinterpret_cast<float*>(smem + TABLE_OFF);
+    float* sa_l = sb_l + BN;
+    unsigned short* bias_l = reinterpret_cast<unsigned short*>(sa_l + BM);
+    if (tid < BN) {
+      sb_l[tid] = sb_reg;
+      bias_l[tid] = bias_reg;
+    }
+    if (tid < BM) sa_l[tid] = sa_reg;
+    const int em0 = m0, en0 = n0, evb = vb;
+    const int nvb = vb + (int)gridDim.x;
+    const bool more = nvb < total;
+    if (more) {
+      const GemmParams& nq = gp.pr[nvb >= nt0 ? 1 : 0];
+      tile_of(nq, nvb >= nt0 ? nvb - nt0 : nvb, m0, n0);
+      set_src(nq, m0, n0);
+      stage_x(0);  // lands under the epilogue
+      load_w(std::integral_constant<int, 0>{});
+      load_tables(nq, m0, n0);
+      ktiles = nq.ktiles;
+    }
+    __syncthreads();  // tables visible
+    gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, false>(
+        gp.pr[evb >= nt0 ? 1 : 0], acc, smem + EPI_OFF + wave * SCRATCH_WAVE, sb_l, sa_l, bias_l, em0,
+        en0, wave, lane);
+    if (!more) break;
+    vb = nvb;
+  }
+}
+
+// fragment-order copy of a weight [N, K] (row stride ldw_b bytes) for gemm_wdirect_kernel: one
+// thread per 16 bytes of the output
+template <int DT>
+__global__ __launch_bounds__(256) void shuffle_weight_kernel(const unsigned char* __restrict__ w,
+                                                             unsigned char* __restrict__ out,
+                                                             int64_t nblocks, int ksteps,
+                                                             int64_t ldw_b) {
+  constexpr int PER = DT == 0 ? 64 : 128;  // 16-B chunks per fragment
+  const int64_t total = nblocks * ksteps * PER;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % PER);
+    const int64_t f = i / PER;
+    const int ks = (int)(f % ksteps);
+    const int64_t nb = f / ksteps;
+    const int half = DT == 0 ? 0 : c >> 6, lane = c & 63;
+    const int rr = lane & 31, hh = lane >> 5;
+    // bf16: k elements 16 ks + 8 hh .. + 8; fp8: k bytes 64 ks + 32 hh + 16 half .. + 16
+    const int64_t kbyte = DT == 0 ? (int64_t)ks * 32 + hh * 16 : (int64_t)ks * 64 + hh * 32 + half * 16;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(w + (nb * 32 + rr) * ldw_b + kbyte);
+    *reinterpret_cast<u32x4*>(out + i * 16) = v;
+  }
+}
+
 // ---- small-M (<= 16 rows) bf16 linear: pure weight streaming ------------------
 // out[m][n] = act( sum_k x[m][k] w[n][k] + bias[n] ).  One wavefront per output
 // channel pair; lanes split K in 16-byte chunks, fp32 accumulate, shuffle reduce.
@@ -632,46 +898,9 @@ int check_common(const mi355_linear_args* a, const char* who) {
   return MI355_OK;
 }
 
-}  // namespace
-
-extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
-  MI355_REQUIRE(a != nullptr, "linear_ex: null args");
-  int rc = check_common(a, "linear_ex");
-  if (rc) return rc;
-  if (a->M == 0) return MI355_OK;
-  hipStream_t st = (hipStream_t)stream;
+// validation of the MFMA path's operands + translation into kernel parameters
+int build_params(const mi355_linear_args* a, GemmParams& p) {
   const int esz = a->fp8 ? 1 : 2;
-  if (!a->fp8 && a->M <= 16 && a->a_map.rows_per_batch == 0 && a->o_map.rows_per_batch == 0 &&
-      !a->gate) {
-    MI355_REQUIRE(a->K % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0,
-                  "linear_bf16: K and strides must be multiples of 8");
-    MI355_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0,
-                  "linear_bf16: operands must be 16-byte aligned");
-    // four channels per wave once there are enough channels to fill the chip that way
-    const int ch = a->N >= 16384 ? 4 : 1;
-    dim3 grid((unsigned)((a->N + 4 * ch - 1) / (4 * ch))), block(256);
-#define SK(MM)                                                                                     \
-  do {                                                                                             \
-    if (ch == 4)                                                                                   \
-      hipLaunchKernelGGL((skinny_linear_kernel<MM, 4>), grid, block, 0, st,                        \
-                         (const unsigned short*)a->a, (const unsigned short*)a->w,                 \
-                         (const unsigned short*)a->bias, (unsigned short*)a->out, (int)a->M,       \
-                         (int)a->N, (int)a->K, a->lda, a->ldw, a->ldo, a->act);                    \
-    else                                                                                           \
-      hipLaunchKernelGGL((skinny_linear_kernel<MM, 1>), grid, block, 0, st,                        \
-                         (const unsigned short*)a->a, (const unsigned short*)a->w,                 \
-                         (const unsigned short*)a->bias, (unsigned short*)a->out, (int)a->M,       \
-                         (int)a->N, (int)a->K, a->lda, a->ldw, a->ldo, a->act);                    \
-  } while (0)
-    if (a->M <= 1) SK(1);
-    else if (a->M <= 2) SK(2);
-    else if (a->M <= 4) SK(4);
-    else if (a->M <= 8) SK(8);
-    else SK(16);
-#undef SK
-    MI355_CHECK_LAUNCH("skinny_linear");
-    return MI355_OK;
-  }
   const int64_t kbytes = a->K * esz;
   MI355_REQUIRE(kbytes % 128 == 0, "linear: K (%ld) must be a multiple of %d", (long)a->K,
                 128 / esz);
@@ -690,7 +919,7 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
   if (a->fp8) MI355_REQUIRE(a->sa && a->sb, "fp8 linear: scales missing");
   MI355_REQUIRE(!a->block_scale || (a->fp8 && a->K % 128 == 0),
                 "linear: block scales need the fp8 path and K %% 128 == 0");
-  GemmParams p;
+  MI355_REQUIRE(((uintptr_t)a->w_shuffled % 16) == 0, "linear: w_shuffled must be 16-byte aligned");
   p.a = (const unsigned char*)a->a;
   p.w = (const unsigned char*)a->w;
   p.sa = a->sa;
@@ -724,14 +953,180 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
     p.sb_sk = a->sb_sk;
     p.sb_sn = a->sb_sn;
   }
+  p.group = ((a->N + 255) / 256) <= 16 ? 2 : 8;
+  p.wsh = (const unsigned char*)a->w_shuffled;
+  p.wsh_ksteps = (int)(kbytes / (a->fp8 ? 64 : 32));
+  return MI355_OK;
+}
+
+// the register-fed weight path needs the fragment-order copy, whole 32-row blocks, and is built
+// for per-token x per-channel (or no) scales only
+bool wdirect_ok(const mi355_linear_args* a) {
+  // Measured 4-9 % SLOWER than the LDS-staged weight on every Flux shape (same bits): the fill
+  // path from L2, not the LDS port, bounds these GEMMs, and register-fed fragments are fetched
+  // by two waves each.  Kept for A/B timing only: MI355_GEMM_WDIRECT=1 turns it on.
+  const bool off = getenv("MI355_GEMM_WDIRECT") == nullptr;  // read per call: tests flip it
+  // per-lane activation offsets are 32-bit: the rows the operand can reach must lie within 4 GiB
+  const int64_t rows = a->a_map.rows_per_batch > 0
+                           ? ((a->M + a->a_map.rows_per_batch - 1) / a->a_map.rows_per_batch) *
+                                     a->a_map.batch_rows + a->a_map.row_offset
+                           : a->M;
+  const bool near = rows * a->lda * (a->fp8 ? 1 : 2) < (1ll << 32);
+  return !off && near && a->w_shuffled != nullptr && !a->block_scale && a->N % 32 == 0 && a->M > 16;
+}
+
+template <int DT>
+int launch_wdirect(const GroupParams& gp, hipStream_t st) {
+  constexpr int LDS = 2 * 256 * 128 + 8 * 32 * 128 + 256 * 4 + 256 * 4 + 256 * 2;
+  static std::atomic<unsigned long long> attr_devices{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
+  auto kfn = gemm_wdirect_kernel<DT>;
+  if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mi355_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MI355_EHIP;
+    }
+    attr_devices.fetch_or(dev_bit, std::memory_order_release);
+  }
+  int64_t total = 0;
+  for (int i = 0; i < gp.nprob; ++i)
+    total += (int64_t)((gp.pr[i].M + 255) / 256) * ((gp.pr[i].N + 255) / 256);
+  dim3 grid((unsigned)std::min<int64_t>(total, resident_workgroups(LDS))), block(512);
+  hipLaunchKernelGGL(kfn, grid, block, LDS, st, gp);
+  MI355_CHECK_LAUNCH("gemm (register-fed weights)");
+  return MI355_OK;
+}
+
+int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hipStream_t st) {
+  if (block_scale)
+    return big ? launch_gemm<1, 4, 2, 2, 4, true>(p, st) : launch_gemm<1, 2, 2, 2, 2, true>(p, st);
+  if (fp8)
+    return big ? launch_gemm<1, 4, 2, 2, 4, false>(p, st) : launch_gemm<1, 2, 2, 2, 2, false>(p, st);
+  return big ? launch_gemm<0, 4, 2, 2, 4, false>(p, st) : launch_gemm<0, 2, 2, 2, 2, false>(p, st);
+}
+
+int launch_small_m(const mi355_linear_args* a, hipStream_t st) {
+  MI355_REQUIRE(a->K % 8 == 0 && a->lda % 8 == 0 && a->ldw % 8 == 0,
+                "linear_bf16: K and strides must be multiples of 8");
+  MI355_REQUIRE(((uintptr_t)a->a % 16) == 0 && ((uintptr_t)a->w % 16) == 0,
+                "linear_bf16: operands must be 16-byte aligned");
+  // four channels per wave once there are enough channels to fill the chip that way
+  const int ch = a->N >= 16384 ? 4 : 1;
+  dim3 grid((unsigned)((a->N + 4 * ch - 1) / (4 * ch))), block(256);
+#define SK(MM)                                                                                     \
+  do {                                                                                             \
+    if (ch == 4)                                                                                   \
+      hipLaunchKernelGGL((skinny_linear_kernel<MM, 4>), grid, block, 0, st,                        \
+                         (const unsigned short*)a->a, (const unsigned short*)a->w,                 \
+                         (const unsigned short*)a->bias, (unsigned short*)a->out, (int)a->M,       \
+                         (int)a->N, (int)a->K, a->lda, a->ldw, a->ldo, a->act);                    \
+    else                                                                                           \
+      hipLaunchKernelGGL((skinny_linear_kernel<MM, 1>), grid, block, 0, st,                        \
+                         (const unsigned short*)a->a, (const unsigned short*)a->w,                 \
+                         (const unsigned short*)a->bias, (unsigned short*)a->out, (int)a->M,       \
+                         (int)a->N, (int)a->K, a->lda, a->ldw, a->ldo, a->act);                    \
+  } while (0)
+  if (a->M <= 1) SK(1);
+  else if (a->M <= 2) SK(2);
+  else if (a->M <= 4) SK(4);
+  else if (a->M <= 8) SK(8);
+  else SK(16);
+#undef SK
+  MI355_CHECK_LAUNCH("skinny_linear");
+  return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
+  MI355_REQUIRE(a != nullptr, "linear_ex: null args");
+  int rc = check_common(a, "linear_ex");
+  if (rc) return rc;
+  if (a->M == 0) return MI355_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (!a->fp8 && a->M <= 16 && a->a_map.rows_per_batch == 0 && a->o_map.rows_per_batch == 0 &&
+      !a->gate)
+    return launch_small_m(a, st);
+  GroupParams gp;
+  rc = build_params(a, gp.pr[0]);
+  if (rc) return rc;
   // Tile choice: 256x256 (8 waves) when the grid still covers the chip, else 128x128.
   const bool big = use_big_tile(a->M, a->N, a->fp8 != 0);
-  if (a->block_scale)
-    return big ? launch_gemm<1, 4, 2, 2, 4, true>(p, st) : launch_gemm<1, 2, 2, 2, 2, true>(p, st);
-  if (a->fp8) {
-    return big ? launch_gemm<1, 4, 2, 2, 4, false>(p, st) : launch_gemm<1, 2, 2, 2, 2, false>(p, st);
+  if (big && wdirect_ok(a)) {
+    gp.pr[1] = gp.pr[0];
+    gp.nprob = 1;
+    return a->fp8 ? launch_wdirect<1>(gp, st) : launch_wdirect<0>(gp, st);
   }
-  return big ? launch_gemm<0, 4, 2, 2, 4, false>(p, st) : launch_gemm<0, 2, 2, 2, 2, false>(p, st);
+  return dispatch_gemm(gp.pr[0], a->fp8 != 0, a->block_scale != 0, big, st);
+}
+
+// Measured (tools/gemm_wdirect_probe.py group, bench.py): sharing a launch buys nothing on the
+// Flux shapes -- the image-stream problem already fills whole rounds of the persistent grid, the
+// text-stream tiles only add a nearly empty extra round, and the text-stream problem alone runs
+// at 1.7 PF/s on 128 x 128 tiles.  The entry point stays (one launch on the register-fed kernel
+// when that is enabled, two launches otherwise); the engine launches the problems one by one.
+extern "C" int mi355_linear_grouped(const mi355_linear_args* args, int count, void* stream) {
+  MI355_REQUIRE(args != nullptr && count >= 1 && count <= 2,
+                "linear_grouped: one or two problems per launch");
+  if (count == 1) return mi355_linear_ex(args, stream);
+  bool one_launch = args[0].fp8 == args[1].fp8 && args[0].M > 16 && args[1].M > 16;
+  int64_t tb = 0;
+  for (int i = 0; i < 2; ++i) {
+    int rc = check_common(&args[i], "linear_grouped");
+    if (rc) return rc;
+    one_launch = one_launch && wdirect_ok(&args[i]);
+    tb += ((args[i].M + 255) / 256) * ((args[i].N + 255) / 256);
+  }
+  // together the problems must still cover the chip with 256 x 256 tiles
+  one_launch = one_launch && tb >= resident_workgroups(128 * 1024) * 3 / 4;
+  if (!one_launch) {
+    for (int i = 0; i < 2; ++i) {
+      int rc = mi355_linear_ex(&args[i], stream);
+      if (rc) return rc;
+    }
+    return MI355_OK;
+  }
+  GroupParams gp;
+  gp.nprob = 2;
+  for (int i = 0; i < 2; ++i) {
+    int rc = build_params(&args[i], gp.pr[i]);
+    if (rc) return rc;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  return args[0].fp8 ? launch_wdirect<1>(gp, st) : launch_wdirect<0>(gp, st);
+}
+
+extern "C" int64_t mi355_shuffled_weight_bytes(int64_t N, int64_t K, int fp8) {
+  if (N <= 0 || K <= 0 || N % 32 != 0 || (K * (fp8 ? 1 : 2)) % 128 != 0) return -1;
+  return N * K * (fp8 ? 1 : 2);
+}
+
+extern "C" int mi355_shuffle_weight(const void* w, void* out, int64_t N, int64_t K, int64_t ldw,
+                                    int fp8, void* stream) {
+  MI355_REQUIRE(w && out, "shuffle_weight: null pointer");
+  const int esz = fp8 ? 1 : 2;
+  MI355_REQUIRE(mi355_shuffled_weight_bytes(N, K, fp8) > 0,
+                "shuffle_weight: N (%ld) must be a multiple of 32 and K (%ld) of %d", (long)N,
+                (long)K, 128 / esz);
+  MI355_REQUIRE(((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0 && (ldw * esz) % 16 == 0,
+                "shuffle_weight: operands must be 16-byte aligned");
+  const int64_t nblocks = N / 32;
+  const int ksteps = (int)(K * esz / (fp8 ? 64 : 32));
+  const int64_t total = nblocks * ksteps * (fp8 ? 128 : 64);
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20);
+  hipStream_t st = (hipStream_t)stream;
+  if (fp8)
+    hipLaunchKernelGGL(shuffle_weight_kernel<1>, dim3(grid), dim3(256), 0, st,
+                       (const unsigned char*)w, (unsigned char*)out, nblocks, ksteps, ldw * esz);
+  else
+    hipLaunchKernelGGL(shuffle_weight_kernel<0>, dim3(grid), dim3(256), 0, st,
+                       (const unsigned char*)w, (unsigned char*)out, nblocks, ksteps, ldw * esz);
+  MI355_CHECK_LAUNCH("shuffle_weight");
+  return MI355_OK;
 }
 
 extern "C" int mi355_fp8_scaled_mm(const void* a, const void* b, const float* sa, const float* sb,

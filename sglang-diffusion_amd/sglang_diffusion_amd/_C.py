@@ -58,6 +58,7 @@ class LinearArgs(ctypes.Structure):
         ("sa_sk", _i64),
         ("sb_sk", _i64),
         ("sb_sn", _i64),
+        ("w_shuffled", _ptr),
     ]
 
 
@@ -92,6 +93,9 @@ SIGNATURES = {
     ),
     "mi355_linear_bf16": (_int, [_ptr, _ptr, _ptr, _ptr] + [_i64] * 6 + [_int, _ptr]),
     "mi355_linear_ex": (_int, [ctypes.POINTER(LinearArgs), _ptr]),
+    "mi355_linear_grouped": (_int, [ctypes.POINTER(LinearArgs), _int, _ptr]),
+    "mi355_shuffled_weight_bytes": (_i64, [_i64, _i64, _int]),
+    "mi355_shuffle_weight": (_int, [_ptr, _ptr, _i64, _i64, _i64, _int, _ptr]),
     "mi355_flash_attn_fwd": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
     "mi355_flash_attn_fwd_f16v": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
     "mi355_bf16_to_f16": (_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
@@ -144,7 +148,7 @@ _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def load_library() -> ctypes.CDLL:
@@ -158,11 +162,17 @@ def load_library() -> ctypes.CDLL:
             "(or __graft_entry__.build()); there is no non-HIP fallback"
         )
     lib = ctypes.CDLL(LIB_PATH)
+    # MI355_DIT_ABI_ANY=1 (A/B timing of an OLDER build through entry points it already had):
+    # symbols the build lacks are skipped and the revision check is waived
+    lenient = os.environ.get("MI355_DIT_ABI_ANY") == "1"
     for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None and lenient:
+            continue
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mi355_abi_version() != ABI_VERSION:
+    if lib.mi355_abi_version() != ABI_VERSION and not lenient:
         raise RuntimeError(f"{LIB_PATH} has ABI {lib.mi355_abi_version()}, this binding expects "
                            f"{ABI_VERSION}: rebuild with `make -C sglang-diffusion_amd/csrc`")
     _lib = lib
@@ -262,14 +272,12 @@ def linear_bf16(x, w, bias, out, act: int = 0) -> None:
     )
 
 
-def linear_ex(
+def _linear_args(
     a, w, out, *, M, N, K, lda, ldw, ldo, sa=None, sb=None, bias=None, residual=None, gate=None,
     ldg=0, gate_rows=0, a_map=None, o_map=None, fp8=False, act=0, f16_cols=None,
-    block_scale=False,
-) -> None:
-    """block_scale: `sa` is the [rows, K/128] group-scale tensor of the activations and `sb` the
-    [N/128, K/128] block-scale tensor of the weight (their strides are taken from the tensors)."""
-    args = LinearArgs()
+    block_scale=False, w_shuffled=None, into: Optional[LinearArgs] = None,
+) -> LinearArgs:
+    args = LinearArgs() if into is None else into
     args.a, args.w, args.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
     args.sa, args.sb, args.bias = _p(sa), _p(sb), _p(bias)
     args.residual, args.gate = _p(residual), _p(gate)
@@ -281,11 +289,48 @@ def linear_ex(
     args.fp8 = int(bool(fp8))
     args.act = int(act)
     args.f16_begin, args.f16_end = (f16_cols if f16_cols else (0, 0))
+    args.block_scale = 0
     if block_scale:
         args.block_scale = 1
         args.sa_sm, args.sa_sk = sa.stride(0), sa.stride(1)
         args.sb_sn, args.sb_sk = sb.stride(0), sb.stride(1)
+    args.w_shuffled = _p(w_shuffled)
+    return args
+
+
+def linear_ex(a, w, out, **kw) -> None:
+    """mi355_linear_ex; keyword arguments as _linear_args.  block_scale: `sa` is the [rows, K/128]
+    group-scale tensor of the activations and `sb` the [N/128, K/128] block-scale tensor of the
+    weight (their strides are taken from the tensors).  w_shuffled: the weight in fragment order
+    (shuffle_weight), enabling the register-fed weight path."""
+    args = _linear_args(a, w, out, **kw)
     _check(load_library().mi355_linear_ex(ctypes.byref(args), _stream(a)), "linear_ex")
+
+
+def linear_grouped(problems) -> None:
+    """One launch for one or two linear problems: `problems` is a list of (a, w, out, kwargs)
+    tuples with linear_ex's arguments."""
+    n = len(problems)
+    arr = (LinearArgs * n)()
+    for i, (a, w, out, kw) in enumerate(problems):
+        _linear_args(a, w, out, into=arr[i], **kw)
+    _check(load_library().mi355_linear_grouped(arr, n, _stream(problems[0][0])), "linear_grouped")
+
+
+def shuffle_weight(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """The weight [N, K] (fp8 or bf16, K contiguous) in MFMA-fragment order for the register-fed
+    weight path, or None when its shape cannot be shuffled (N % 32, K bytes % 128)."""
+    N, K = w.shape
+    fp8 = w.dtype == torch.float8_e4m3fn
+    if not fp8 and w.dtype != torch.bfloat16:
+        raise TypeError(f"shuffle_weight: fp8 or bf16 weight expected, got {w.dtype}")
+    nbytes = load_library().mi355_shuffled_weight_bytes(N, K, int(fp8))
+    if nbytes < 0 or w.stride(1) != 1:
+        return None
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _check(load_library().mi355_shuffle_weight(w.data_ptr(), out.data_ptr(), N, K, w.stride(0),
+                                               int(fp8), _stream(w)), "shuffle_weight")
+    return out
 
 
 # ----------------------------------------------------------------- attention --

@@ -231,30 +231,38 @@ class FluxEngine:
         return ws
 
     # ---------------------------------------------------------------------- helpers --
-    def _lin(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
-             gate=None, gate_rows=0, act=0, ldo=None, lda=None, f16_cols=None):
-        big = _uses_big_tile(M, pk.N, pk.fp8, a.device)
-        self._run(("gemm_fp8blk" if pk.block else "gemm_fp8" if pk.fp8 else "gemm_bf16")
-                  + ("_256" if big else "_128"),
-                  2.0 * M * pk.N * pk.K,
-                  (M * pk.K + pk.N * pk.K) * (1 if pk.fp8 else 2) + 2.0 * M * pk.N,
-                  _C.linear_ex, a, pk.w, out, M=M, N=pk.N, K=pk.K, lda=lda or a.stride(0),
-                  ldw=pk.w.stride(0), ldo=ldo or out.stride(0), sa=sa, sb=pk.s, bias=pk.b,
-                  residual=residual, gate=gate, ldg=gate.stride(0) if gate is not None else 0,
-                  gate_rows=gate_rows, a_map=a_map, o_map=o_map, fp8=pk.fp8, act=act,
-                  f16_cols=f16_cols, block_scale=pk.block)
+    def _prob(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
+              gate=None, gate_rows=0, act=0, ldo=None, lda=None, f16_cols=None):
+        """One quantised (or packed) projection as a linear problem: (kind, flops, bytes, a, w,
+        out, kwargs of _C.linear_ex)."""
+        kind = "gemm_fp8blk" if pk.block else "gemm_fp8" if pk.fp8 else "gemm_bf16"
+        kw = dict(M=M, N=pk.N, K=pk.K, lda=lda or a.stride(0), ldw=pk.w.stride(0),
+                  ldo=ldo or out.stride(0), sa=sa, sb=pk.s, bias=pk.b, residual=residual, gate=gate,
+                  ldg=gate.stride(0) if gate is not None else 0, gate_rows=gate_rows, a_map=a_map,
+                  o_map=o_map, fp8=pk.fp8, act=act, f16_cols=f16_cols, block_scale=pk.block)
+        return (kind, 2.0 * M * pk.N * pk.K,
+                (M * pk.K + pk.N * pk.K) * (1 if pk.fp8 else 2) + 2.0 * M * pk.N, a, pk.w, out, kw)
 
-    def _lin_mod(self, mod, a, out, *, M, o_map=None, residual=None, gate=None, gate_rows=0, act=0):
-        """Unquantised nn.Linear-style module (FF, embedders)."""
+    def _prob_mod(self, mod, a, out, *, M, o_map=None, residual=None, gate=None, gate_rows=0, act=0):
+        """Unquantised nn.Linear-style module (FF, embedders) as a linear problem."""
         w = mod.weight.data
         N, K = w.shape
-        big = _uses_big_tile(M, N, False, a.device)
-        self._run("gemm_bf16" + ("_256" if big else "_128"), 2.0 * M * N * K,
-                  2.0 * (M * K + N * K + M * N), _C.linear_ex, a, w,
-                  out, M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldo=out.stride(0),
-                  bias=mod.bias.data if mod.bias is not None else None, residual=residual,
-                  gate=gate, ldg=gate.stride(0) if gate is not None else 0, gate_rows=gate_rows,
-                  o_map=o_map, fp8=False, act=act)
+        kw = dict(M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldo=out.stride(0),
+                  bias=mod.bias.data if mod.bias is not None else None, residual=residual, gate=gate,
+                  ldg=gate.stride(0) if gate is not None else 0, gate_rows=gate_rows, o_map=o_map,
+                  fp8=False, act=act)
+        return ("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), a, w, out, kw)
+
+    def _launch(self, prob):
+        kind, flops, nbytes, a, w, out, kw = prob
+        big = _uses_big_tile(kw["M"], kw["N"], kw["fp8"], a.device)
+        self._run(kind + ("_256" if big else "_128"), flops, nbytes, _C.linear_ex, a, w, out, **kw)
+
+    def _lin(self, pk: _Packed, a, out, **kw):
+        self._launch(self._prob(pk, a, out, **kw))
+
+    def _lin_mod(self, mod, a, out, **kw):
+        self._launch(self._prob_mod(mod, a, out, **kw))
 
     # --------------------------------------------------------------------------- step --
     def step(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance,
@@ -347,14 +355,22 @@ class FluxEngine:
             if fn is not None:
                 fn(kind, i, joint3)
 
+        def pair(img, txt):
+            """The image- and the text-stream problem of one projection (the text one on the
+            second stream when that is on).  Sharing ONE launch was measured and buys nothing:
+            the image problem fills whole rounds of the persistent grid by itself."""
+            self._launch(img)
+            with on_text_stream():
+                self._launch(txt)
+
         for i, blk in enumerate(self.dbl):
             tell("before", "d", i)
             oi, ot = self.mod_off[("d", i, "img")], self.mod_off[("d", i, "txt")]
             a, sa = norm_in(blk["qkv"].fp8, chunk(oi, 0), chunk(oi, 1), Ti, map_i, Mi)
-            self._lin(blk["qkv"], a, qkv, M=Mi, sa=sa, o_map=map_i, f16_cols=vcols)
             with on_text_stream():
-                a, sa = norm_in(blk["add_qkv"].fp8, chunk(ot, 0), chunk(ot, 1), Tt, map_t, Mt, "_t")
-                self._lin(blk["add_qkv"], a, qkv, M=Mt, sa=sa, o_map=map_t, f16_cols=vcols)
+                at, sat = norm_in(blk["add_qkv"].fp8, chunk(ot, 0), chunk(ot, 1), Tt, map_t, Mt, "_t")
+            pair(self._prob(blk["qkv"], a, qkv, M=Mi, sa=sa, o_map=map_i, f16_cols=vcols),
+                 self._prob(blk["add_qkv"], at, qkv, M=Mt, sa=sat, o_map=map_t, f16_cols=vcols))
             if side is not None:
                 main.wait_event(side.record_event())
             # RMSNorm + RoPE: in place on k; the attention kernel does q's as it loads Q
@@ -372,19 +388,22 @@ class FluxEngine:
                 side.wait_event(main.record_event())
             # output projections, then the feed-forward (never quantised); gate and residual
             # are folded into the GEMM that ends each half
-            for (po, f1, f2, off, T, rmap, M, sfx) in (
-                    (blk["to_out"], blk["ff1"], blk["ff2"], oi, Ti, map_i, Mi, ""),
-                    (blk["to_add_out"], blk["cff1"], blk["cff2"], ot, Tt, map_t, Mt, "_t")):
-                with (on_text_stream() if sfx else contextlib.nullcontext()):
-                    self._lin(po, a_src, joint, M=M, sa=a_s, a_map=rmap, o_map=rmap,
-                              residual=joint, gate=chunk(off, 2), gate_rows=T)
-                    xn = ws["xn" + sfx]
-                    self._run("elementwise", 0.0, 4.0 * M * D, _C.layernorm_modulate, xn, joint,
-                              chunk(off, 3), chunk(off, 4), B, T, 1e-6, x_map=rmap)
-                    ffh = ws["ffh" + sfx][:M]
-                    self._lin_mod(f1, xn[:M], ffh, M=M, act=1)
-                    self._lin_mod(f2, ffh, joint, M=M, o_map=rmap, residual=joint,
-                                  gate=chunk(off, 5), gate_rows=T)
+            pair(self._prob(blk["to_out"], a_src, joint, M=Mi, sa=a_s, a_map=map_i, o_map=map_i,
+                            residual=joint, gate=chunk(oi, 2), gate_rows=Ti),
+                 self._prob(blk["to_add_out"], a_src, joint, M=Mt, sa=a_s, a_map=map_t, o_map=map_t,
+                            residual=joint, gate=chunk(ot, 2), gate_rows=Tt))
+            self._run("elementwise", 0.0, 4.0 * Mi * D, _C.layernorm_modulate, ws["xn"], joint,
+                      chunk(oi, 3), chunk(oi, 4), B, Ti, 1e-6, x_map=map_i)
+            with on_text_stream():
+                self._run("elementwise", 0.0, 4.0 * Mt * D, _C.layernorm_modulate, ws["xn_t"], joint,
+                          chunk(ot, 3), chunk(ot, 4), B, Tt, 1e-6, x_map=map_t)
+            ffh, ffh_t = ws["ffh"][:Mi], ws["ffh_t"][:Mt]
+            pair(self._prob_mod(blk["ff1"], ws["xn"][:Mi], ffh, M=Mi, act=1),
+                 self._prob_mod(blk["cff1"], ws["xn_t"][:Mt], ffh_t, M=Mt, act=1))
+            pair(self._prob_mod(blk["ff2"], ffh, joint, M=Mi, o_map=map_i, residual=joint,
+                                gate=chunk(oi, 5), gate_rows=Ti),
+                 self._prob_mod(blk["cff2"], ffh_t, joint, M=Mt, o_map=map_t, residual=joint,
+                                gate=chunk(ot, 5), gate_rows=Tt))
             tell("after", "d", i)
         if side is not None:
             main.wait_event(side.record_event())

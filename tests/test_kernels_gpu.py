@@ -776,3 +776,77 @@ def test_empty_inputs_are_no_ops(device):
     _C.cfg_normalize(torch.empty(0, 8, **bf), torch.empty(0, 8, **bf), 1.0)
     _C.guidance_rescale(torch.empty(0, 8, **bf), torch.empty(0, 8, **bf), 0.7)
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------ grouped / register-fed GEMMs --
+@pytest.mark.parametrize("fp8", [True, False])
+def test_grouped_linear_equals_two_launches(device, fp8, monkeypatch):
+    """mi355_linear_grouped: the image- and the text-stream problem of a double block in one
+    launch (row maps into a joint buffer, gate + residual epilogue, half-format columns) give
+    the very bits of two mi355_linear_ex launches; so does the register-fed weight path
+    (mi355_shuffle_weight + MI355_GEMM_WDIRECT=1), alone and grouped."""
+    from sglang_diffusion_amd import _C
+
+    B, Ti, Tt, K, N = 2, 2304, 200, 256, 512
+    S = Ti + Tt
+    g = torch.Generator(device=device).manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device=device, generator=g)  # noqa: E731
+    if fp8:
+        act = (rnd(B * S, K) * 50).clamp(-448, 448).to(torch.float8_e4m3fn)
+        ws = [(rnd(N, K) * 50).clamp(-448, 448).to(torch.float8_e4m3fn) for _ in range(2)]
+        sa = torch.rand(B * S, device=device, generator=g) * 0.01
+        sbs = [torch.rand(N, device=device, generator=g) * 0.01 for _ in range(2)]
+    else:
+        act = rnd(B * S, K).bfloat16()
+        ws = [(rnd(N, K) * 0.05).bfloat16() for _ in range(2)]
+        sa, sbs = None, [None, None]
+    biases = [rnd(N).bfloat16() for _ in range(2)]
+    gates = [rnd(B, N).bfloat16() for _ in range(2)]
+    resid = rnd(B * S, N).bfloat16()
+    maps = ((Ti, S, Tt), (Tt, S, 0))
+
+    def problems(out, shuffled, epilogue):
+        ps = []
+        for i, (T, mp) in enumerate(zip((Ti, Tt), maps)):
+            kw = dict(M=B * T, N=N, K=K, lda=K, ldw=K, ldo=N, sa=sa, sb=sbs[i], bias=biases[i],
+                      a_map=mp, o_map=mp, fp8=fp8)
+            if epilogue == "gate":
+                kw.update(residual=out, gate=gates[i], ldg=N, gate_rows=T)
+            else:
+                kw.update(f16_cols=(N // 2, N), act=1 if i == 0 else 0)
+            if shuffled:
+                kw["w_shuffled"] = _C.shuffle_weight(ws[i])
+            ps.append((act, ws[i], out, kw))
+        return ps
+
+    for epilogue in ("gate", "f16"):
+        want = resid.clone()
+        for a, w, o, kw in problems(want, False, epilogue):
+            _C.linear_ex(a, w, o, **kw)
+        got = resid.clone()
+        _C.linear_grouped(problems(got, False, epilogue))
+        assert torch.equal(got, want), epilogue
+        monkeypatch.setenv("MI355_GEMM_WDIRECT", "1")
+        got2, got3 = resid.clone(), resid.clone()
+        _C.linear_grouped(problems(got2, True, epilogue))
+        for a, w, o, kw in problems(got3, True, epilogue):
+            _C.linear_ex(a, w, o, **kw)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("MI355_GEMM_WDIRECT")
+        assert torch.equal(got2, want) and torch.equal(got3, want), epilogue
+    # shapes that cannot be shuffled are reported, not mangled
+    assert _C.shuffle_weight(torch.zeros(40, 256, dtype=torch.bfloat16, device=device)) is None
+    # a pair that cannot share a launch (mixed dtypes) still computes both problems
+    x = rnd(64, 128).bfloat16()
+    w = rnd(32, 128).bfloat16()
+    o1, o2 = torch.zeros(64, 32, dtype=torch.bfloat16, device=device), torch.zeros(
+        64, 32, dtype=torch.bfloat16, device=device)
+    kw = dict(M=64, N=32, K=128, lda=128, ldw=128, ldo=32)
+    xq = (rnd(64, 128) * 20).to(torch.float8_e4m3fn)
+    wq = (rnd(32, 128) * 20).to(torch.float8_e4m3fn)
+    s1, s2 = torch.ones(64, device=device), torch.ones(32, device=device)
+    _C.linear_grouped([(x, w, o1, kw), (xq, wq, o2, dict(kw, fp8=True, sa=s1, sb=s2))])
+    r1, r2 = torch.empty_like(o1), torch.empty_like(o2)
+    _C.linear_ex(x, w, r1, **kw)
+    _C.linear_ex(xq, wq, r2, **dict(kw, fp8=True, sa=s1, sb=s2))
+    assert torch.equal(o1, r1) and torch.equal(o2, r2)
