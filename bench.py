@@ -58,8 +58,8 @@ def flux_step_flops(B: int, S: int = 4608, D: int = 3072, n_double: int = 19, n_
     return dict(fp8=float(fp8), bf16=float(bf16), attn=float(attn), total=float(fp8 + bf16 + attn))
 
 
-def launch_ranks(n: int, argv, timeout_s: float = 3300.0) -> int:
-    """Start `n` copies of this script as rank processes and wait for them.  Returns the exit
+def launch_ranks(n: int, argv, timeout_s: float = 3300.0, script: str = None) -> int:
+    """Start `n` copies of this script (or of `script`) as rank processes and wait for them.  Returns the exit
     code for the parent: 0 when every rank exited 0, else the first failing rank's code (the
     remaining ranks are terminated by PID).  Rank 0 inherits stdout (it prints the JSON line);
     the other ranks' stdout goes to stderr."""
@@ -71,7 +71,7 @@ def launch_ranks(n: int, argv, timeout_s: float = 3300.0) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + list(argv),
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(script or __file__)] + list(argv),
                                       env=env, stdout=None if r == 0 else sys.stderr))
     deadline = time.time() + timeout_s
     rc = 0

@@ -328,8 +328,9 @@ class USPAttention(nn.Module):
                                      torch.cat([v[:, :num_rep, hs], vs], dim=1), md)
         out_shard = ulysses_all_to_all(out[:, num_rep:].contiguous(), group, scatter_dim=1,
                                        gather_dim=2)
-        parts = [torch.empty_like(out[:, :num_rep]) for _ in range(P)]
-        dist.all_gather(parts, out[:, :num_rep].contiguous(), group=group)
+        from ..runtime.parallel import all_gather_tensors
+
+        parts = all_gather_tensors(out[:, :num_rep], group)
         return torch.cat([torch.cat(parts, dim=2), out_shard], dim=1)
 
 
@@ -406,9 +407,9 @@ class UlyssesAttention(nn.Module):
             rep_out = out[:, n_main:]
             out = out[:, :n_main]
             if P > 1:
-                parts = [torch.empty_like(rep_out) for _ in range(P)]
-                dist.all_gather(parts, rep_out.contiguous(), group=group)
-                rep_out = torch.cat(parts, dim=2)
+                from ..runtime.parallel import all_gather_tensors
+
+                rep_out = torch.cat(all_gather_tensors(rep_out, group), dim=2)
         if P > 1:
             out = ulysses_all_to_all(out.contiguous(), group, scatter_dim=1, gather_dim=2)
         return out, rep_out

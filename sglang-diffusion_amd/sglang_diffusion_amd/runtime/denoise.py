@@ -115,9 +115,14 @@ class DenoisingStage:
                     # the reference broadcasts rank 0's norm / std scalars (denoising.py:
                     # 1448-1478); here rank 0's conditional prediction itself travels (2 MB), so
                     # both ranks run the same two kernels on the same operands
+                    from .parallel import _wire
+
                     cond = mine if not neg else torch.empty_like(mine)
-                    dist.broadcast(cond, src=dist.get_global_rank(self.cfg_group, 0),
+                    wire = _wire(cond, self.cfg_group)   # host-staged under gloo
+                    dist.broadcast(wire, src=dist.get_global_rank(self.cfg_group, 0),
                                    group=self.cfg_group)
+                    if wire is not cond:
+                        cond.copy_(wire)
                     self._post_cfg(batch, noise_pred, cond)
                 return noise_pred
             if self.cfg_batched:

@@ -47,6 +47,27 @@ def _wire(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def all_gather_tensors(x: torch.Tensor, group=None) -> List[torch.Tensor]:
+    """dist.all_gather of equally shaped tensors; under gloo, device tensors travel through the
+    host and come back on x's device."""
+    P = dist.get_world_size(group)
+    w = _wire(x.contiguous(), group)
+    parts = [torch.empty_like(w) for _ in range(P)]
+    dist.all_gather(parts, w, group=group)
+    return [t.to(x.device) for t in parts] if w.device != x.device else parts
+
+
+def _a2a(recv: torch.Tensor, send: torch.Tensor, group) -> None:
+    """all_to_all_single into `recv` (host-staged under gloo)."""
+    w = _wire(send, group)
+    if w.device == send.device:
+        dist.all_to_all_single(recv, send, group=group)
+        return
+    r = torch.empty(recv.shape, dtype=recv.dtype, device="cpu")
+    dist.all_to_all_single(r, w, group=group)
+    recv.copy_(r)
+
+
 def gather_latents(local: torch.Tensor, counts: Sequence[int], group=None) -> Optional[torch.Tensor]:
     """Gather per-rank final latents [n_r, ...] to rank 0 (once per batch).  Ranks may hold
     different request counts: pad to the maximum, all_gather, trim."""
@@ -150,7 +171,7 @@ def ulysses_all_to_all(x: torch.Tensor, group, scatter_dim: int, gather_dim: int
     if scatter_dim == 2:   # heads out, sequence in: [B, S, H, D] -> [B, P*S, H/P, D]
         send = x.reshape(B, S, P, H // P, D).permute(2, 0, 1, 3, 4).contiguous()  # [P, B, S, H/P, D]
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=group)
+        _a2a(recv, send, group)
         if B == 1:
             return recv.view(1, P * S, H // P, D)
         return recv.permute(1, 0, 2, 3, 4).reshape(B, P * S, H // P, D)
@@ -160,7 +181,7 @@ def ulysses_all_to_all(x: torch.Tensor, group, scatter_dim: int, gather_dim: int
     else:
         send = x.reshape(B, P, S // P, H, D).permute(1, 0, 2, 3, 4).contiguous()
     recv = torch.empty((P, B, S // P, H, D), dtype=x.dtype, device=x.device)
-    dist.all_to_all_single(recv, send, group=group)
+    _a2a(recv, send, group)
     return recv.permute(1, 2, 0, 3, 4).reshape(B, S // P, P * H, D)
 
 
@@ -208,12 +229,14 @@ def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group=None
     nxt = dist.get_global_rank(group, (rank + 1) % P) if group is not None else (rank + 1) % P
     prv = dist.get_global_rank(group, (rank - 1) % P) if group is not None else (rank - 1) % P
     k_cur, v_cur = k.contiguous(), v.contiguous()
+    staged = k_cur.is_cuda and dist.get_backend(group) == "gloo"  # gloo moves host memory only
     out = lse = None
     for step in range(P):
         reqs = []
         if step + 1 < P:
-            k_nxt, v_nxt = torch.empty_like(k_cur), torch.empty_like(v_cur)
-            ops = [dist.P2POp(dist.isend, k_cur, nxt, group), dist.P2POp(dist.isend, v_cur, nxt, group),
+            k_snd, v_snd = (k_cur.cpu(), v_cur.cpu()) if staged else (k_cur, v_cur)
+            k_nxt, v_nxt = torch.empty_like(k_snd), torch.empty_like(v_snd)
+            ops = [dist.P2POp(dist.isend, k_snd, nxt, group), dist.P2POp(dist.isend, v_snd, nxt, group),
                    dist.P2POp(dist.irecv, k_nxt, prv, group), dist.P2POp(dist.irecv, v_nxt, prv, group)]
             reqs = dist.batch_isend_irecv(ops)
         o_s, lse_s = attn_fn(q, k_cur, v_cur, scale)
@@ -224,7 +247,7 @@ def ring_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, group=None
         for r in reqs:
             r.wait()
         if step + 1 < P:
-            k_cur, v_cur = k_nxt, v_nxt
+            k_cur, v_cur = (k_nxt.to(k.device), v_nxt.to(v.device)) if staged else (k_nxt, v_nxt)
     return out, lse
 
 
@@ -252,5 +275,6 @@ def cfg_parallel_combine(noise_pred_local: torch.Tensor, guidance_scale: float, 
     scale_fn = scale_fn or _hip_scale
     s = float(guidance_scale)
     partial = scale_fn(noise_pred_local, s if dist.get_rank(group) == 0 else 1.0 - s)
-    dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
-    return partial
+    w = _wire(partial, group)
+    dist.all_reduce(w, op=dist.ReduceOp.SUM, group=group)
+    return partial if w is partial else partial.copy_(w)
