@@ -87,7 +87,10 @@ int mi355_per_tensor_quant_fp8(const void* x, int64_t numel, void* q, float* s,
  * out[M,N] = bf16( (A[M,K] . B[K,N]) * sa[m] * sb[n] + bias[n] ), fp32 accumulate.
  * a: fp8 row-major, row stride lda.  b: fp8 COLUMN-major [K,N], i.e. the
  * weight W[N,K] with row stride ldb.  sa fp32 [M], sb fp32 [N], bias bf16 [N]
- * or NULL.  K % 128 == 0, lda/ldb % 16 == 0, N % 8 == 0, ldo % 8 == 0. */
+ * or NULL.  K % 128 == 0, lda/ldb % 16 == 0, N % 8 == 0, ldo % 8 == 0.
+ * Restriction against the reference op: out_dtype is bf16 only.  The reference also builds
+ * the fp16 epilogue (sgl-kernel/tests/test_fp8_gemm.py:17-35 runs both); the DiT path is bf16
+ * throughout, so the registry wrapper raises for any other out_dtype instead of converting. */
 int mi355_fp8_scaled_mm(const void* a, const void* b, const float* sa, const float* sb,
                         const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                         int64_t lda, int64_t ldb, int64_t ldo, void* stream);

@@ -186,8 +186,15 @@ def _check(rc: int, what: str) -> None:
 
 
 def _stream(t: torch.Tensor) -> int:
+    """The launch stream for an op on `t`: the current stream of t's device.  The library keys
+    its per-device state (function attributes, CU counts, symbol addresses) on the CURRENT
+    device, so a tensor on another device is refused instead of being launched with the wrong
+    device's state."""
     if not t.is_cuda:
         raise RuntimeError("mi355 kernels need tensors on a HIP device (got a CPU tensor)")
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on cuda:{t.device.index} but the current device is cuda:"
+                           f"{torch.cuda.current_device()}: wrap the call in torch.cuda.device(...)")
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -672,6 +679,8 @@ def cfg_normalize(noise, cond, factor: float, scratch=None) -> None:
     if not (noise.is_contiguous() and cond.is_contiguous()) or noise.shape != cond.shape:
         raise RuntimeError("cfg_normalize: contiguous tensors of one shape expected")
     scratch = _cfg_scratch(noise) if scratch is None else scratch
+    if scratch.numel() < 256 or scratch.dtype != torch.float32:
+        raise RuntimeError("cfg_normalize: scratch needs 256 fp32 elements")
     _check(
         load_library().mi355_cfg_normalize(
             noise.data_ptr(), cond.data_ptr(), float(factor), noise.numel(), scratch.data_ptr(),

@@ -37,7 +37,25 @@ def prepare_sigmas(num_inference_steps: int) -> np.ndarray:
     return np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
 
 
+def shift_sigmas(sigmas: np.ndarray, *, mu: Optional[float], shift: float, kind: str) -> np.ndarray:
+    """The schedule warp of the flow-match sampler.  With `mu` (dynamic shifting, what Flux
+    uses): sigma' = e^mu / (e^mu + (1/sigma - 1)) ("exponential", scheduling_flow_match_euler_
+    discrete.py:628-634) or mu / (mu + (1/sigma - 1)) ("linear", :636-639); without it the
+    static form shift * sigma / (1 + (shift - 1) * sigma) (:375-379)."""
+    if mu is None:
+        return shift * sigmas / (1 + (shift - 1) * sigmas)
+    lead = np.exp(mu) if kind == "exponential" else mu
+    return lead / (lead + (1 / sigmas - 1) ** 1.0)
+
+
 class FlowMatchEulerDiscreteScheduler:
+    """The part of the reference scheduler the DiT denoise loop uses: a sigma schedule that is
+    either handed in (`sigmas=`, the Flux pipeline's linspace(1, 1/N, N)) or the default ramp
+    over the training range, warped by `shift_sigmas`, a trailing 0, and the Euler update.
+    Options of the reference class that no pipeline on this path sets -- custom `timesteps`,
+    `invert_sigmas`, `shift_terminal`, stochastic sampling -- raise instead of being carried
+    along untested."""
+
     order = 1
 
     def __init__(self, num_train_timesteps: int = 1000, shift: float = 1.0,
@@ -48,26 +66,25 @@ class FlowMatchEulerDiscreteScheduler:
                  stochastic_sampling: bool = False):
         if time_shift_type not in {"exponential", "linear"}:
             raise ValueError("`time_shift_type` must either be 'exponential' or 'linear'.")
-        if stochastic_sampling:
-            raise NotImplementedError("stochastic sampling is not on the Flux path")
+        for name, on in (("stochastic_sampling", stochastic_sampling), ("invert_sigmas", invert_sigmas),
+                         ("shift_terminal", shift_terminal)):
+            if on:
+                raise NotImplementedError(f"{name} is not on the Flux / HunyuanVideo denoise path")
         self.num_train_timesteps = num_train_timesteps
         self.use_dynamic_shifting = use_dynamic_shifting
-        self.invert_sigmas = invert_sigmas
-        self.shift_terminal = shift_terminal
         self.time_shift_type = time_shift_type
-        timesteps = np.linspace(1, num_train_timesteps, num_train_timesteps,
-                                dtype=np.float32)[::-1].copy()
-        timesteps = torch.from_numpy(timesteps).to(dtype=torch.float32)
-        sigmas = timesteps / num_train_timesteps
-        if not use_dynamic_shifting:
-            sigmas = shift * sigmas / (1 + (shift - 1) * sigmas)
-        self.timesteps = sigmas * num_train_timesteps
+        self._shift = shift
         self._step_index: Optional[int] = None
         self._begin_index: Optional[int] = None
-        self._shift = shift
-        self.sigmas = sigmas.to("cpu")
-        self.sigma_min = self.sigmas[-1].item()
-        self.sigma_max = self.sigmas[0].item()
+        # before set_timesteps: the training ramp 1 .. 1/T (statically shifted unless dynamic)
+        ramp = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+        sig = torch.from_numpy(ramp) / num_train_timesteps
+        if not use_dynamic_shifting:
+            sig = shift * sig / (1 + (shift - 1) * sig)
+        self.sigmas = sig
+        self.timesteps = sig * num_train_timesteps
+        self._timesteps_host = self.timesteps
+        self.sigma_min, self.sigma_max = sig[-1].item(), sig[0].item()
 
     @property
     def shift(self) -> float:
@@ -84,76 +101,42 @@ class FlowMatchEulerDiscreteScheduler:
     def set_begin_index(self, begin_index: int = 0) -> None:
         self._begin_index = begin_index
 
-    def _sigma_to_t(self, sigma: float) -> float:
-        return sigma * self.num_train_timesteps
-
-    def _time_shift_exponential(self, mu, sigma, t):
-        if isinstance(t, np.ndarray):
-            return np.exp(mu) / (np.exp(mu) + (1 / t - 1) ** sigma)
-        return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
-
-    def _time_shift_linear(self, mu, sigma, t):
-        return mu / (mu + (1 / t - 1) ** sigma)
-
     def time_shift(self, mu, sigma, t):
-        if self.time_shift_type == "exponential":
-            return self._time_shift_exponential(mu, sigma, t)
-        return self._time_shift_linear(mu, sigma, t)
+        if sigma != 1.0:
+            raise NotImplementedError("time_shift with an exponent other than 1")
+        return shift_sigmas(np.asarray(t, dtype=np.float64) if not isinstance(t, np.ndarray) else t,
+                            mu=mu, shift=self._shift, kind=self.time_shift_type)
 
     def set_timesteps(self, num_inference_steps: Optional[int] = None, device=None,
                       sigmas: Optional[List[float]] = None, mu: Optional[float] = None,
                       timesteps: Optional[List[float]] = None) -> None:
+        """scheduling_flow_match_euler_discrete.py:267-411 for the two callers on this path:
+        set_timesteps(sigmas=..., mu=...) and set_timesteps(num_inference_steps)."""
+        if timesteps is not None:
+            raise NotImplementedError("custom `timesteps` are not on the Flux / HunyuanVideo path")
         if self.use_dynamic_shifting and mu is None:
             raise ValueError("`mu` must be passed when `use_dynamic_shifting` is set to be `True`")
-        if sigmas is not None and timesteps is not None and len(sigmas) != len(timesteps):
-            raise ValueError("`sigmas` and `timesteps` should have the same length")
-        if num_inference_steps is not None:
-            if (sigmas is not None and len(sigmas) != num_inference_steps) or (
-                    timesteps is not None and len(timesteps) != num_inference_steps):
+        if sigmas is None:
+            if num_inference_steps is None:
+                raise ValueError("Either num_inference_steps, sigmas, or timesteps must be provided")
+            # the default ramp, in timestep units as the reference builds it (float64)
+            base = np.linspace(self.sigma_max * self.num_train_timesteps,
+                               self.sigma_min * self.num_train_timesteps,
+                               num_inference_steps) / self.num_train_timesteps
+        else:
+            base = np.array(sigmas).astype(np.float32)      # the reference narrows to fp32 here
+            if num_inference_steps is not None and len(base) != num_inference_steps:
                 raise ValueError("`sigmas` and `timesteps` should have the same length as "
                                  "num_inference_steps, if `num_inference_steps` is provided")
-        else:
-            if sigmas is not None:
-                num_inference_steps = len(sigmas)
-            elif timesteps is not None:
-                num_inference_steps = len(timesteps)
-            else:
-                raise ValueError("Either num_inference_steps, sigmas, or timesteps must be provided")
-        self.num_inference_steps = num_inference_steps
-        is_timesteps_provided = timesteps is not None
-        timesteps_array = np.array(timesteps).astype(np.float32) if is_timesteps_provided else None
-        if sigmas is None:
-            if timesteps_array is None:
-                timesteps_array = np.linspace(self._sigma_to_t(self.sigma_max),
-                                              self._sigma_to_t(self.sigma_min),
-                                              num_inference_steps)
-            sigmas_array = timesteps_array / self.num_train_timesteps
-        else:
-            sigmas_array = np.array(sigmas).astype(np.float32)
-            num_inference_steps = len(sigmas_array)
-        if self.use_dynamic_shifting:
-            sigmas_array = self.time_shift(mu, 1.0, sigmas_array)
-        else:
-            sigmas_array = self.shift * sigmas_array / (1 + (self.shift - 1) * sigmas_array)
-        if self.shift_terminal:
-            one_minus_z = 1 - sigmas_array
-            scale_factor = one_minus_z[-1] / (1 - self.shift_terminal)
-            sigmas_array = 1 - (one_minus_z / scale_factor)
-        sigmas_tensor = torch.from_numpy(np.asarray(sigmas_array)).to(dtype=torch.float32)
-        if not is_timesteps_provided:
-            timesteps_tensor = sigmas_tensor * self.num_train_timesteps
-        else:
-            timesteps_tensor = torch.from_numpy(timesteps_array).to(dtype=torch.float32)
-        if self.invert_sigmas:
-            sigmas_tensor = 1.0 - sigmas_tensor
-            timesteps_tensor = sigmas_tensor * self.num_train_timesteps
-            sigmas_tensor = torch.cat([sigmas_tensor, torch.ones(1)])
-        else:
-            sigmas_tensor = torch.cat([sigmas_tensor, torch.zeros(1)])
+        self.num_inference_steps = len(base)
+        warped = shift_sigmas(base, mu=mu if self.use_dynamic_shifting else None,
+                              shift=self._shift, kind=self.time_shift_type)
+        sig = torch.from_numpy(np.asarray(warped)).to(dtype=torch.float32)
+        ts = sig * self.num_train_timesteps
         # sigmas stay on the host (they parameterise kernel launches); timesteps go to `device`
-        self.sigmas = sigmas_tensor
-        self.timesteps = timesteps_tensor.to(device) if device is not None else timesteps_tensor
-        self._timesteps_host = timesteps_tensor
+        self.sigmas = torch.cat([sig, torch.zeros(1)])
+        self._timesteps_host = ts
+        self.timesteps = ts.to(device) if device is not None else ts
         self._step_index = None
         self._begin_index = None
 

@@ -63,6 +63,22 @@ class DenoisingStage:
         self.cfg_batched = cfg_batched
         self.attn_metadata_builder = Mi355AttentionMetadataBuilder()
         self._freqs = {}
+        self._bufs = {}  # per-shape scratch and staging tensors: a step allocates nothing
+
+    def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
+        key = (name, tuple(shape), dtype, str(device))
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(tuple(shape), dtype=dtype, device=device)
+        return t
+
+    def cfg_batched_inputs(self, batch: Req, guidance):
+        """The step-invariant operands of the batched cond|uncond forward (text states, pooled
+        vectors, guidance), concatenated once per request batch instead of once per step."""
+        return dict(
+            encoder_hidden_states=torch.cat([batch.prompt_embeds, batch.negative_prompt_embeds], 0),
+            pooled_projections=torch.cat([batch.pooled_embeds, batch.neg_pooled_embeds], 0),
+            guidance=None if guidance is None else torch.cat([guidance, guidance], 0))
 
     @staticmethod
     @lru_cache(maxsize=8)
@@ -90,15 +106,18 @@ class DenoisingStage:
         return self.transformer.forward_fused(**kw) if self.fused else self.transformer(**kw)
 
     def predict_noise_with_cfg(self, batch: Req, latent_model_input, timestep, guidance, freqs,
-                               step_index: int):
+                               step_index: int, cfg_inputs=None):
         md = self.attn_metadata_builder.build(current_timestep=step_index)
         with set_forward_context(current_timestep=step_index, attn_metadata=md,
                                  forward_batch=batch):
             if not batch.do_classifier_free_guidance:
-                return self._dit(hidden_states=latent_model_input,
-                                 encoder_hidden_states=batch.prompt_embeds,
-                                 pooled_projections=batch.pooled_embeds, timestep=timestep,
-                                 guidance=guidance, freqs_cis=freqs).clone()
+                out = self._dit(hidden_states=latent_model_input,
+                                encoder_hidden_states=batch.prompt_embeds,
+                                pooled_projections=batch.pooled_embeds, timestep=timestep,
+                                guidance=guidance, freqs_cis=freqs)
+                # the engine's output buffer is overwritten by its next call: hand out a copy
+                # held in a per-shape buffer of the stage
+                return self._buf("noise", out.shape, out.dtype, out.device).copy_(out)
             if self.cfg_group is not None:
                 import torch.distributed as dist
 
@@ -128,16 +147,18 @@ class DenoisingStage:
             if self.cfg_batched:
                 # cond and uncond of every request ride in ONE forward of batch 2B: rows of a
                 # batch never interact inside the DiT, so this equals two separate passes.
-                out = self._dit(
-                    hidden_states=torch.cat([latent_model_input, latent_model_input], 0),
-                    encoder_hidden_states=torch.cat([batch.prompt_embeds,
-                                                     batch.negative_prompt_embeds], 0),
-                    pooled_projections=torch.cat([batch.pooled_embeds, batch.neg_pooled_embeds], 0),
-                    timestep=torch.cat([timestep, timestep], 0),
-                    guidance=None if guidance is None else torch.cat([guidance, guidance], 0),
-                    freqs_cis=freqs)
-                cond, uncond = out.chunk(2, dim=0)
-                cond, uncond = cond.contiguous(), uncond.contiguous()
+                if cfg_inputs is None:
+                    cfg_inputs = self.cfg_batched_inputs(batch, guidance)
+                B = latent_model_input.shape[0]
+                x2 = self._buf("cfg_x", (2 * B,) + tuple(latent_model_input.shape[1:]),
+                               latent_model_input.dtype, latent_model_input.device)
+                x2[:B].copy_(latent_model_input)
+                x2[B:].copy_(latent_model_input)
+                t2 = self._buf("cfg_t", (2 * B,), timestep.dtype, timestep.device)
+                t2[:B].copy_(timestep)
+                t2[B:].copy_(timestep)
+                out = self._dit(hidden_states=x2, timestep=t2, freqs_cis=freqs, **cfg_inputs)
+                cond, uncond = out[:B], out[B:]          # contiguous halves of the engine's output
             else:
                 cond = self._dit(hidden_states=latent_model_input,
                                  encoder_hidden_states=batch.prompt_embeds,
@@ -147,7 +168,7 @@ class DenoisingStage:
                                    encoder_hidden_states=batch.negative_prompt_embeds,
                                    pooled_projections=batch.neg_pooled_embeds, timestep=timestep,
                                    guidance=guidance, freqs_cis=freqs).clone()
-        noise_pred = torch.empty_like(cond)
+        noise_pred = self._buf("cfg_noise", cond.shape, cond.dtype, cond.device)
         _C.cfg_combine(noise_pred, cond, uncond, float(batch.guidance_scale))
         self._post_cfg(batch, noise_pred, cond)
         return noise_pred
@@ -157,13 +178,17 @@ class DenoisingStage:
         return bool(batch.cfg_normalization and float(batch.cfg_normalization) > 0) or \
             batch.guidance_rescale > 0.0
 
-    @staticmethod
-    def _post_cfg(batch: Req, noise_pred, cond) -> None:
-        """denoising.py:1490-1506, in place on noise_pred."""
+    def _post_cfg(self, batch: Req, noise_pred, cond) -> None:
+        """denoising.py:1490-1506, in place on noise_pred; the moment scratch is kept per batch
+        size."""
+        scratch = None
+        if self._wants_post_cfg(batch) and noise_pred.is_cuda:
+            scratch = self._buf("cfg_moments", (256 * max(1, noise_pred.shape[0]),), torch.float32,
+                                noise_pred.device)
         if batch.cfg_normalization and float(batch.cfg_normalization) > 0:
-            _C.cfg_normalize(noise_pred, cond, float(batch.cfg_normalization))
+            _C.cfg_normalize(noise_pred, cond, float(batch.cfg_normalization), scratch)
         if batch.guidance_rescale > 0.0:
-            _C.guidance_rescale(noise_pred, cond, float(batch.guidance_rescale))
+            _C.guidance_rescale(noise_pred, cond, float(batch.guidance_rescale), scratch)
 
     @torch.no_grad()
     def forward(self, batch: Req, num_steps: Optional[int] = None) -> Req:
@@ -202,11 +227,19 @@ class DenoisingStage:
         latents = batch.latents
         ts_host = self.scheduler._timesteps_host
         n = len(ts_host) if num_steps is None else min(num_steps, len(ts_host))
+        cfg_inputs = (self.cfg_batched_inputs(batch, guidance)
+                      if (batch.do_classifier_free_guidance and self.cfg_batched
+                          and self.cfg_group is None) else None)
         for i in range(n):
             latent_model_input = latents.to(torch.bfloat16)
             timestep = timesteps[i].repeat(bsz)  # sigma*1000, fp32; the model does not rescale
             noise_pred = self.predict_noise_with_cfg(batch, latent_model_input, timestep, guidance,
-                                                     freqs, i)
-            latents = self.scheduler.step(noise_pred, ts_host[i], latents)[0]
-        batch.latents = latents
+                                                     freqs, i, cfg_inputs)
+            # the update ping-pongs between two buffers of the stage (never in place: the
+            # input of step 0 belongs to the caller)
+            nxt = (self._buf(f"latents{i & 1}", latents.shape, noise_pred.dtype, device)
+                   if latents.is_cuda else None)
+            latents = self.scheduler.step(noise_pred, ts_host[i], latents, out=nxt)[0]
+        # a fresh tensor for the caller: the stage's buffers are reused by its next batch
+        batch.latents = latents.clone() if n > 0 else latents
         return batch
