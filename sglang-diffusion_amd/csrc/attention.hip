@@ -52,10 +52,78 @@ struct AttnParams {
   float q_eps;
   const float* qcos;
   const float* qsin;
+  int ablate;  // timing experiments only (MI355_ATTN_ABLATE): bit 0 = no K/V refills after the
+               // first tiles, bit 1 = per-phase clocks of workgroup 0 into lse (two-phase kernel)
 };
 
 __device__ __forceinline__ int k_swz(int key) { return key & 15; }
 __device__ __forceinline__ int v_swz(int key) { return ((key & 3) << 2) | ((key >> 2) & 3); }
+
+// Q fragments of one wave: B operand, lane -> query row q0 + r, d = 16s + 8hh + 0..7
+template <int D, int KSTEPS>
+__device__ __forceinline__ void load_q_fragments(const AttnParams& p, int b, int head, int q0, int r,
+                                                 int hh, bf16x8 (&qf)[KSTEPS]) {
+  int qrow = q0 + r;
+  if (qrow >= p.Sq) qrow = p.Sq - 1;
+  const unsigned short* qp = p.q + b * p.q_sb + (int64_t)qrow * p.q_ss + head * p.q_sh;
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * hh);
+  if (p.qw1 || p.qcos) {
+    // per-head RMSNorm and interleaved RoPE of the query while it is loaded.  Same arithmetic and
+    // summation order as qk_norm_rope_kernel (elementwise.hip), where 16 (or 8) lanes hold one
+    // row in 8-element chunks: here chunk 2s + hh of the row sits in step s of this lane and
+    // chunk 2s + (1 - hh) in the lane 32 away, so the butterfly over chunk-index bits 3, 2, 1
+    // runs inside the lane and bit 0 is one exchange.
+    float f[KSTEPS][8];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[s][j] = (float)qf[s][j];
+    const float* wsel = qrow < p.q_split ? p.qw0 : p.qw1;
+    if (wsel) {
+      float c2[KSTEPS];
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        c2[s] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c2[s] += f[s][j] * f[s][j];
+      }
+#pragma unroll
+      for (int w = KSTEPS / 2; w >= 1; w >>= 1)
+#pragma unroll
+        for (int s = 0; s < w; ++s) c2[s] = c2[s] + c2[s + w];
+      const float sq = c2[0] + __shfl_xor(c2[0], 32, 64);
+      const float rs = rsqrtf(sq / (float)D + p.q_eps);
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const f32x4 wa = reinterpret_cast<const f32x4*>(wsel)[2 * (2 * s + hh)];
+        const f32x4 wb = reinterpret_cast<const f32x4*>(wsel)[2 * (2 * s + hh) + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f[s][j] = rbf((f[s][j] * rs) * wa[j]);
+          f[s][4 + j] = rbf((f[s][4 + j] * rs) * wb[j]);
+        }
+      }
+    }
+    if (p.qcos) {
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const f32x4 cs = reinterpret_cast<const f32x4*>(p.qcos + (int64_t)qrow * (D / 2))[2 * s + hh];
+        const f32x4 sn = reinterpret_cast<const f32x4*>(p.qsin + (int64_t)qrow * (D / 2))[2 * s + hh];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x1 = f[s][2 * j], x2 = f[s][2 * j + 1];
+          f[s][2 * j] = fmaf(-x2, sn[j], __fmul_rn(x1, cs[j]));
+          f[s][2 * j + 1] = fmaf(x1, sn[j], __fmul_rn(x2, cs[j]));
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)f[s][j];
+  }
+}
 
 // D = head size (128 or 64).  KV tile = 64 keys.
 // F16: V holds IEEE half values and P is rounded to half (11 significant bits instead of
@@ -101,70 +169,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
   const int hk = head / (p.H / p.Hk);
   const int q0 = qb * (NW * 32) + wave * 32;
 
-  // ---- Q fragments: B operand, lane -> query row r, d = 16s + 8hh + 0..7 ----
   bf16x8 qf[KSTEPS];
-  {
-    int qrow = q0 + r;
-    if (qrow >= p.Sq) qrow = p.Sq - 1;
-    const unsigned short* qp = p.q + b * p.q_sb + (int64_t)qrow * p.q_ss + head * p.q_sh;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
-      qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s + 8 * hh);
-    if (p.qw1 || p.qcos) {
-      // Same arithmetic and summation order as qk_norm_rope_kernel (elementwise.hip), where 16
-      // (or 8) lanes hold one row in 8-element chunks: here chunk 2s + hh of the row sits in
-      // step s of this lane and chunk 2s + (1 - hh) in the lane 32 away, so the butterfly over
-      // chunk-index bits 3, 2, 1 runs inside the lane and bit 0 is one exchange.
-      float f[KSTEPS][8];
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[s][j] = (float)qf[s][j];
-      const float* wsel = qrow < p.q_split ? p.qw0 : p.qw1;
-      if (wsel) {
-        float c[KSTEPS];
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          c[s] = 0.f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) c[s] += f[s][j] * f[s][j];
-        }
-#pragma unroll
-        for (int w = KSTEPS / 2; w >= 1; w >>= 1)
-#pragma unroll
-          for (int s = 0; s < w; ++s) c[s] = c[s] + c[s + w];
-        const float sq = c[0] + __shfl_xor(c[0], 32, 64);
-        const float rs = rsqrtf(sq / (float)D + p.q_eps);
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          const f32x4 wa = reinterpret_cast<const f32x4*>(wsel)[2 * (2 * s + hh)];
-          const f32x4 wb = reinterpret_cast<const f32x4*>(wsel)[2 * (2 * s + hh) + 1];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f[s][j] = rbf((f[s][j] * rs) * wa[j]);
-            f[s][4 + j] = rbf((f[s][4 + j] * rs) * wb[j]);
-          }
-        }
-      }
-      if (p.qcos) {
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-          const f32x4 cs = reinterpret_cast<const f32x4*>(p.qcos + (int64_t)qrow * (D / 2))[2 * s + hh];
-          const f32x4 sn = reinterpret_cast<const f32x4*>(p.qsin + (int64_t)qrow * (D / 2))[2 * s + hh];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float x1 = f[s][2 * j], x2 = f[s][2 * j + 1];
-            f[s][2 * j] = fmaf(-x2, sn[j], __fmul_rn(x1, cs[j]));
-            f[s][2 * j + 1] = fmaf(x1, sn[j], __fmul_rn(x2, cs[j]));
-          }
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)f[s][j];
-    }
-  }
+  load_q_fragments<D, KSTEPS>(p, b, head, q0, r, hh, qf);
 
   // ---- LDS-DMA sources: piece = 1 KiB = 1024/ROWB rows; [K tile | V tile] ----
   // A full tile is fetched as (wave-uniform tile base) + (loop-invariant 32-bit lane offset):
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
     const int k0 = t * KV;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < ntiles) stage(cur ^ 1, k0 + KV);
+    if (t + 1 < ntiles && !(p.ablate == 1 && t > 0)) stage(cur ^ 1, k0 + KV);
     const unsigned char* kt = smem + cur * STAGE_BYTES;
     const unsigned char* vt = kt + TILE_BYTES;
 
@@ -276,6 +282,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+    // MFMA phases run at raised wave priority: when the SIMD's other wave is in its softmax, the
+    // matrix unit is fed first (about 1 % at the Flux shape)
+    __builtin_amdgcn_s_setprio(2);
     {
       bf16x8 kf[2][2];  // [parity of step][kb]
 #pragma unroll
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
           sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s & 1][kb], qf[s], sacc[kb], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // mask keys past the end (last tile only; wave-uniform branch)
     if (k0 + KV > p.Sk) {
 #pragma unroll
@@ -353,6 +363,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
         }
     }
     l_run += rs;
+    __builtin_amdgcn_s_setprio(2);
 
     // ---- O^T += V^T P^T ---------------------------------------------------------
 #pragma unroll
@@ -395,6 +406,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
             oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][st], oacc[d], 0, 0, 0);
           }
         }
+    __builtin_amdgcn_s_setprio(0);
   };
   for (int t = 0; t < ntiles; t += 2) {
     tile_body(std::integral_constant<int, 0>{}, t);
@@ -434,6 +446,412 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
       }
     }
   }
+}
+
+// ---- two-phase ("ping-pong") variant: head size 128, 8 waves ----------------------------------
+// attn_fwd_kernel runs every wave through  S = K Q^T (MFMA) -> softmax (vector) -> O += V^T P
+// (MFMA)  behind one barrier per tile, so the two waves that share a SIMD are always in the SAME
+// phase: they queue for the matrix unit together, then for the vector unit together, and each
+// unit idles while the other works (measured: a tile costs about the SUM of its MFMA and vector
+// time).  Here a wave's iteration is regrouped into an MFMA block [O += V_{j-1}^T P_{j-1}, then
+// S_j = K_j Q^T, interleaved] and a vector block [softmax of S_j], two barriers per tile split
+// the time into half steps, and waves 4..7 run one half step behind waves 0..3: while one wave
+// of a SIMD is in its MFMA block the other is in its vector block.  Same arithmetic in the same
+// order as attn_fwd_kernel, so results are identical to the bit.
+//   half step 2j   : waves 0-3  MFMA block j          waves 4-7  softmax of tile j-1
+//   half step 2j+1 : waves 0-3  softmax of tile j     waves 4-7  MFMA block j
+// K_j is read in half steps 2j, 2j+1 and V_j in 2j+2, 2j+3, so K and V each have a two-slot ring:
+// at half step 2j the refills for K_{j+1} and V_j are issued (64 KiB of LDS, every offset an
+// immediate).
+// Measured at B=4, S=4608, H=24 (same box): 1120-1330 us against 930-980 us for attn_fwd_kernel,
+// whose waves drift apart inside a tile and overlap on their own; the two workgroup-wide barriers
+// per tile cost more than the forced alternation gains.  Kept behind MI355_ATTN_PINGPONG=1 as a
+// measured negative result.
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pingpong_kernel(AttnParams p) {
+  constexpr int D = 128, NW = 8, KV = 64;
+  constexpr int ROWB = D * 2;
+  constexpr int CPR = ROWB / 16;
+  constexpr int TILE_BYTES = KV * ROWB;
+  constexpr int V_RING = 2 * TILE_BYTES;         // LDS: K slot 0 | K slot 1 | V slot 0 | V slot 1
+  constexpr int PIECES = TILE_BYTES / 1024 / NW;  // 1-KiB DMA pieces per wave per K (or V) tile
+  constexpr int KSTEPS = D / 16;
+  constexpr int DVB = D / 32;
+  typedef typename std::conditional<F16, f16x8, bf16x8>::type pfrag_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int hh = lane >> 5;
+  // which of a SIMD's two waves this is: a workgroup's waves are dealt to the four SIMDs
+  // cyclically, so waves w and w + 4 share one (pairing w with w ^ 1 instead: 1430 us vs 1120)
+  const int late = wave >> 2;
+
+  int qb, head, b;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = total >> 3, rem = total & 7, xcd = lin & 7;
+    const unsigned wid =
+        (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (lin >> 3);
+    qb = (int)(wid % gx);
+    const unsigned bh = wid / gx;
+    head = (int)(bh % gy);
+    b = (int)(bh / gy);
+  }
+  const int hk = head / (p.H / p.Hk);
+  const int q0 = qb * (NW * 32) + wave * 32;
+
+  bf16x8 qf[KSTEPS];
+  load_q_fragments<D, KSTEPS>(p, b, head, q0, r, hh, qf);
+
+  // ---- LDS-DMA sources (as attn_fwd_kernel) -------------------------------------------------
+  const unsigned char* kbase =
+      reinterpret_cast<const unsigned char*>(p.k + b * p.k_sb + hk * p.k_sh);
+  const unsigned char* vbase =
+      reinterpret_cast<const unsigned char*>(p.v + b * p.v_sb + hk * p.v_sh);
+  // (row, swizzled chunk) of the 16-byte slot this lane fills in piece i of a K or V tile
+  auto piece_slot = [&](int i, bool isv, int& row, int& chunk) __attribute__((always_inline)) {
+    const int slot = (wave + NW * i) * 64 + lane;
+    row = slot / CPR;
+    const int pc = slot % CPR;
+    chunk = isv ? (pc ^ (v_swz(row) & (CPR - 1))) : (pc ^ (k_swz(row) & (CPR - 1)));
+  };
+  unsigned int koffg[PIECES], voffg[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    int row, chunk;
+    piece_slot(i, false, row, chunk);
+    koffg[i] = (unsigned int)(row * p.k_ss * 2 + chunk * 16);
+    piece_slot(i, true, row, chunk);
+    voffg[i] = (unsigned int)(row * p.v_ss * 2 + chunk * 16);
+  }
+  const int64_t k_tile_step = (int64_t)KV * p.k_ss * 2, v_tile_step = (int64_t)KV * p.v_ss * 2;
+  // K (ISV = false) or V tile `t` -> its ring slot t & 1
+  auto stage = [&](auto slotc, auto isvc, int t) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slotc)::value;
+    constexpr bool ISV = decltype(isvc)::value;
+    unsigned char* dst = smem + (ISV ? V_RING : 0) + SLOT * TILE_BYTES;
+    const unsigned char* base = ISV ? vbase : kbase;
+    const int k0 = t * KV;
+    if (k0 + KV <= p.Sk) {
+      const unsigned char* t0 = base + (int64_t)t * (ISV ? v_tile_step : k_tile_step);
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(t0 + (ISV ? voffg[i] : koffg[i])),
+                                         (lds_ptr_t)(dst + (wave + NW * i) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        int row, chunk;
+        piece_slot(i, ISV, row, chunk);  // the partial last tile only: recomputed, not kept live
+        int key = k0 + row;
+        if (key >= p.Sk) key = p.Sk - 1;
+        const unsigned char* src = base + ((int64_t)key * (ISV ? p.v_ss : p.k_ss) * 2 + chunk * 16);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + (wave + NW * i) * 1024),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  // ---- per-lane LDS read offsets (as attn_fwd_kernel) ---------------------------------------
+  // K row read: row r, chunk (2s + hh) ^ (r & 15).  The k-step only enters through bits 5..7,
+  // which the rest of the offset leaves clear: offset(s) = offset(0) ^ (s << 5), one register
+  // instead of eight.
+  const int koff0 = r * ROWB + ((hh ^ (k_swz(r) & (CPR - 1))) << 4);
+  const int li = lane & 15, qq = li >> 2, pp = li & 3, g2 = (lane >> 4) & 1;
+  int vlane[DVB][2];
+#pragma unroll
+  for (int d = 0; d < DVB; ++d)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int key = half * 8 + 4 * hh + qq;
+      const int col = d * 32 + g2 * 16 + 4 * pp;
+      vlane[d][half] =
+          key * ROWB + ((((col >> 3) ^ (v_swz(key) & (CPR - 1)))) << 4) + ((col & 7) << 1);
+    }
+
+  f32x16 oacc[DVB];
+#pragma unroll
+  for (int d = 0; d < DVB; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  f32x16 sacc[2];    // raw scores of the tile whose MFMA block ran last
+  pfrag_t pf[2][2];  // its probabilities after the vector block: [32-key block][16-key step]
+  float m_run = -INFINITY;
+  float l_run = 0.f;
+  const float c = p.scale_log2;
+  constexpr float LAZY_LOG2 = 8.0f;
+  const int ntiles = (p.Sk + KV - 1) / KV;
+
+  auto v_frag = [&](const unsigned char* vt, int key0, int d) __attribute__((always_inline)) {
+    const int o0 = vlane[d][0] + key0 * ROWB, o1 = vlane[d][1] + key0 * ROWB;
+    if constexpr (F16) {
+      const f16x4 t0 = __builtin_bit_cast(
+          f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                     (__attribute__((address_space(3))) hw_f16x4*)(vt + o0)));
+      const f16x4 t1 = __builtin_bit_cast(
+          f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                     (__attribute__((address_space(3))) hw_f16x4*)(vt + o1)));
+      return (pfrag_t)__builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(vt + o0));
+      const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+          (__attribute__((address_space(3))) bf16x4*)(vt + o1));
+      return (pfrag_t)__builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto pv_mfma = [&](const pfrag_t& vf, const pfrag_t& pfr, f32x16& acc) __attribute__((always_inline)) {
+    if constexpr (F16) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfr, acc, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pfr, acc, 0, 0, 0);
+  };
+
+  // MFMA block of tile j (K in slot BUF = j & 1): O += V_{j-1}^T P_{j-1} (V in the other slot) and
+  // S_j = K_j Q^T, one MFMA of each in turn; fragments are read AHEAD steps before their MFMAs.
+  // DO_PV / DO_QK drop one of the two for the first and the last block.
+  auto mfma_block = [&](auto bufc, auto do_pv, auto do_qk) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    constexpr bool DO_PV = decltype(do_pv)::value, DO_QK = decltype(do_qk)::value;
+    const unsigned char* kt = smem + BUF * TILE_BYTES;
+    const unsigned char* vt = smem + V_RING + (BUF ^ 1) * TILE_BYTES;
+    constexpr int AHEAD = 2, NSTEP = 16;  // 3, 4, 6 steps ahead: spills, no faster
+    __builtin_amdgcn_s_setprio(3);
+    bf16x8 kf[AHEAD + 1];
+    pfrag_t vf[AHEAD + 1];
+    // step g: S chain kb = g & 1, k-step g >> 1;  O accumulator d = g & 3 of 16-key step g >> 2
+    auto fetch = [&](int g) __attribute__((always_inline)) {
+      if constexpr (DO_QK)
+        kf[g % (AHEAD + 1)] =
+            *reinterpret_cast<const bf16x8*>(kt + (g & 1) * 32 * ROWB + (koff0 ^ ((g >> 1) << 5)));
+      if constexpr (DO_PV) vf[g % (AHEAD + 1)] = v_frag(vt, (g >> 2) * 16, g & 3);
+    };
+    if constexpr (DO_QK) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) fetch(g);
+#pragma unroll
+    for (int g = 0; g < NSTEP; ++g) {
+      if (g + AHEAD < NSTEP) fetch(g + AHEAD);
+      if constexpr (DO_QK)
+        sacc[g & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g % (AHEAD + 1)], qf[g >> 1],
+                                                              sacc[g & 1], 0, 0, 0);
+      if constexpr (DO_PV) pv_mfma(vf[g % (AHEAD + 1)], pf[g >> 3][(g >> 2) & 1], oacc[g & 3]);
+    }
+    // the order the machine scheduler must produce: reads stay AHEAD steps in front
+    constexpr int RD = (DO_QK ? 1 : 0) + (DO_PV ? 2 : 0), MF = (DO_QK ? 1 : 0) + (DO_PV ? 1 : 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, RD * AHEAD, 0);
+#pragma unroll
+    for (int g = 0; g < NSTEP - AHEAD; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+    }
+#pragma unroll
+    for (int g = NSTEP - AHEAD; g < NSTEP; ++g) __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // vector block of tile t: online softmax of sacc -> pf, exactly as in attn_fwd_kernel
+  auto softmax_tile = [&](int t) __attribute__((always_inline)) {
+    const int k0 = t * KV;
+    if (k0 + KV > p.Sk) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (key >= p.Sk) sacc[kb][e] = -INFINITY;
+        }
+    }
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const bool outgrown = (mx - m_run) * c > LAZY_LOG2;
+    if (__builtin_amdgcn_ballot_w64(outgrown) != 0) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DVB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    }
+    const float mc = m_run * c;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pe[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        pe[e] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], c, -mc));
+        rs += pe[e];
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if constexpr (F16) pf[kb][st][j] = (_Float16)pe[8 * st + j];
+          else pf[kb][st][j] = (__bf16)pe[8 * st + j];
+        }
+    }
+    l_run += rs;
+  };
+
+  constexpr std::true_type YES{};
+  constexpr std::false_type NO{};
+  constexpr std::integral_constant<int, 0> S0{};
+  constexpr std::integral_constant<int, 1> S1{};
+  // timing experiment (MI355_ATTN_ABLATE bit 1): shader clocks spent in MFMA blocks, vector
+  // blocks and waiting at barriers, per wave
+  unsigned long long tk = 0, t_mfma = 0, t_vec = 0, t_bar = 0;
+  auto lap = [&](unsigned long long& acc) __attribute__((always_inline)) {
+    if (p.ablate & 2) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      acc += now - tk;
+      tk = now;
+    }
+  };
+  auto wait_and_sync = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    lap(t_bar);
+  };
+  auto sync = [&]() __attribute__((always_inline)) {
+    __syncthreads();
+    lap(t_bar);
+  };
+  // the two half steps of tile j (1 <= j < ntiles, J2 = j & 1) for the early / the late waves
+  auto tile_steps = [&](auto latec, auto j2c, int j) __attribute__((always_inline)) {
+    constexpr bool LATE = decltype(latec)::value;
+    constexpr int J2 = decltype(j2c)::value;
+    wait_and_sync();  // half step 2j: K_j and V_{j-1} have landed
+    if (!(p.ablate == 1 && j > 1)) {
+      if (j + 1 < ntiles) stage(std::integral_constant<int, J2 ^ 1>{}, NO, j + 1);
+      stage(j2c, YES, j);
+    }
+    if constexpr (LATE) {
+      softmax_tile(j - 1);
+      lap(t_vec);
+    } else {
+      mfma_block(j2c, YES, YES);
+      lap(t_mfma);
+    }
+    sync();  // half step 2j + 1
+    if constexpr (LATE) {
+      mfma_block(j2c, YES, YES);
+      lap(t_mfma);
+    } else {
+      softmax_tile(j);
+      lap(t_vec);
+    }
+  };
+  auto run = [&](auto latec) __attribute__((always_inline)) {
+    constexpr bool LATE = decltype(latec)::value;
+    // tile 0: nothing to multiply into O yet
+    wait_and_sync();
+    if (ntiles > 1) stage(S1, NO, 1);
+    stage(S0, YES, 0);
+    if constexpr (!LATE) mfma_block(S0, NO, YES);
+    __syncthreads();
+    if (p.ablate & 2) tk = __builtin_amdgcn_s_memtime();
+    if constexpr (LATE) mfma_block(S0, NO, YES);
+    else softmax_tile(0);
+    for (int j = 1; j < ntiles; j += 2) {
+      tile_steps(latec, S1, j);
+      if (j + 1 < ntiles) tile_steps(latec, S0, j + 1);
+    }
+    // after the last tile: its V^T P product only
+    wait_and_sync();
+    auto last = [&]() __attribute__((always_inline)) {
+      if (ntiles & 1) mfma_block(S1, YES, NO);
+      else mfma_block(S0, YES, NO);
+    };
+    if constexpr (LATE) softmax_tile(ntiles - 1);
+    else last();
+    __syncthreads();
+    if constexpr (LATE) last();
+  };
+  stage(S0, NO, 0);
+  if (late) run(YES);
+  else run(NO);
+
+  // ---- finish: combine the two half-row sums, normalise, store -------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv_l = 1.0f / l_tot;
+  const int qrow = q0 + r;
+  const bool q_ok = qrow < p.Sq;
+  if (p.lse && q_ok && hh == 0) {
+    p.lse[((int64_t)b * p.H + head) * p.Sq + qrow] =
+        (m_run * c + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+  unsigned short* op = p.o + b * p.o_sb + (int64_t)(q_ok ? qrow : 0) * p.o_ss + head * p.o_sh;
+#pragma unroll
+  for (int d = 0; d < DVB; ++d) {
+    unsigned int pk[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      pk[g][0] = pack_bf2(oacc[d][4 * g] * inv_l, oacc[d][4 * g + 1] * inv_l);
+      pk[g][1] = pack_bf2(oacc[d][4 * g + 2] * inv_l, oacc[d][4 * g + 3] * inv_l);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2) {
+        auto sw = __builtin_amdgcn_permlane32_swap(pk[g][w2], pk[g + 1][w2], false, false);
+        pk[g][w2] = sw[0];
+        pk[g + 1][w2] = sw[1];
+      }
+      if (q_ok) {
+        const int dv8 = d * 32 + 8 * (g + hh);
+        *reinterpret_cast<u32x4*>(op + dv8) = u32x4{pk[g][0], pk[g][1], pk[g + 1][0], pk[g + 1][1]};
+      }
+    }
+  }
+  if ((p.ablate & 2) && p.lse) {
+    // written over the start of lse after every row of workgroup 0 has been stored
+    __syncthreads();
+    if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+      p.lse[3 * wave] = (float)t_mfma;
+      p.lse[3 * wave + 1] = (float)t_vec;
+      p.lse[3 * wave + 2] = (float)t_bar;
+    }
+  }
+}
+
+template <bool F16>
+int launch_attn_pingpong(const AttnParams& p, hipStream_t st) {
+  constexpr int LDS = 2 * 2 * 64 * 128 * 2;
+  static std::atomic<unsigned long long> attr_devices{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
+  auto kfn = attn_fwd_pingpong_kernel<F16>;
+  if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mi355_set_error("flash_attn_fwd: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MI355_EHIP;
+    }
+    attr_devices.fetch_or(dev_bit, std::memory_order_release);
+  }
+  dim3 grid((unsigned)((p.Sq + 255) / 256), (unsigned)p.H, (unsigned)p.B), block(512);
+  hipLaunchKernelGGL(kfn, grid, block, LDS, st, p);
+  MI355_CHECK_LAUNCH("flash_attn_fwd (two-phase)");
+  return MI355_OK;
 }
 
 template <int D, bool TRREAD, bool F16, int NW = 4>
@@ -534,7 +952,13 @@ static int attn_entry(const void* q, const void* k, const void* v, void* out, fl
   p.q_eps = q_eps;
   p.qcos = qcos;
   p.qsin = qsin;
+  {
+    const char* ab = getenv("MI355_ATTN_ABLATE");
+    p.ablate = ab ? atoi(ab) : 0;
+  }
   hipStream_t st = (hipStream_t)stream;
+  if (D == 128 && getenv("MI355_ATTN_PINGPONG") != nullptr)
+    return v_f16 ? launch_attn_pingpong<true>(p, st) : launch_attn_pingpong<false>(p, st);
   if (v_f16) return D == 128 ? launch_attn<128, true, true>(p, st) : launch_attn<64, true, true>(p, st);
   static const bool no_tr = getenv("MI355_ATTN_NO_TR") != nullptr;  // debugging aid
   if (no_tr)

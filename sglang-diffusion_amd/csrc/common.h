@@ -133,14 +133,39 @@ __device__ __forceinline__ int64_t map_row32(int m, int rpb, int64_t brows, int6
 // more accurate closed form would NOT match it).  tanh(u) = sign(u) * (1 - d),
 // d = 2e/(1+e), e = exp(-2|u|) on the hardware exp2/rcp units; d is accurate to ~1e-7
 // relative, so fl(1 - d) is the correctly rounded tanh up to rare double roundings.
+// The operation sequence is spelled out (no contraction left to the compiler) so that the scalar
+// form and the two-at-a-time form below give the same bits.
 __device__ __forceinline__ float gelu_tanh_f(float x) {
+#pragma clang fp contract(off)
   const float kBeta = 0.7978845608028654f;
   const float kKappa = 0.044715f;
-  const float u = kBeta * (x + kKappa * x * x * x);
+  const float p = (kKappa * x) * x;
+  const float u = kBeta * fmaf(p, x, x);
   const float e = __builtin_amdgcn_exp2f(fabsf(u) * -2.8853900817779268f);  // exp(-2|u|)
-  const float d = 2.0f * e * __builtin_amdgcn_rcpf(1.0f + e);
+  const float d = (2.0f * e) * __builtin_amdgcn_rcpf(1.0f + e);
   const float th = copysignf(1.0f - d, u);
   return (0.5f * x) * (1.0f + th);
+}
+// Two values at a time: the plain multiplies / adds / fmas become packed fp32 instructions
+// (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32: two results per issue slot); exp2 and rcp stay
+// one per value.  A GEMM epilogue with this activation is VALU-bound and not overlapped with
+// MFMAs, so the instruction count is its time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_tanh_f2(f32x2 x) {
+#pragma clang fp contract(off)
+  const f32x2 kBeta = f32x2{0.7978845608028654f, 0.7978845608028654f};
+  const f32x2 kKappa = f32x2{0.044715f, 0.044715f};
+  const f32x2 one = f32x2{1.0f, 1.0f};
+  const f32x2 p = (kKappa * x) * x;
+  const f32x2 u = kBeta * __builtin_elementwise_fma(p, x, x);
+  const f32x2 au = __builtin_elementwise_abs(u) * f32x2{-2.8853900817779268f, -2.8853900817779268f};
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(au[0]), __builtin_amdgcn_exp2f(au[1])};
+  const f32x2 den = one + e;
+  const f32x2 rc = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  const f32x2 d = (f32x2{2.0f, 2.0f} * e) * rc;
+  const f32x2 omd = one - d;
+  const f32x2 th = f32x2{copysignf(omd[0], u[0]), copysignf(omd[1], u[1])};
+  return (f32x2{0.5f, 0.5f} * x) * (one + th);
 }
 __device__ __forceinline__ float silu_f(float x) {
   return x / (1.0f + __expf(-x));

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void activation_kernel(unsigned short* __restr
     float f[8];
     unpack8(reinterpret_cast<const u32x4*>(x + row * ldx)[c], f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = act == 0 ? silu_f(f[j]) : gelu_tanh_f(f[j]);
+    for (int j = 0; j < 8; ++j) f[j] = act == 0 ? silu_f(f[j]) : gelu_tanh_f(f[j]);  // (scalar form: same bits as the GEMM epilogue's paired one)
     reinterpret_cast<u32x4*>(out + row * ldo)[c] = pack8(f);
   }
 }

@@ -117,8 +117,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             // (python/sglang/srt/layers/quantization/fp8_utils.py:546-548)
             if constexpr (BLOCKSCALE) v = rbf(v);
             v += bsv[e];
-            if (p.act == MI355_ACT_GELU_TANH) v = gelu_tanh_f(rbf(v));
             y[e] = v;
+          }
+          if (p.act == MI355_ACT_GELU_TANH) {
+            const f32x2 g0 = gelu_tanh_f2(f32x2{rbf(y[0]), rbf(y[1])});
+            const f32x2 g1 = gelu_tanh_f2(f32x2{rbf(y[2]), rbf(y[3])});
+            y[0] = g0[0];
+            y[1] = g0[1];
+            y[2] = g1[0];
+            y[3] = g1[1];
           }
           if (as_f16) {
             pk[g][0] = pack_bf2_as_f16(y[0], y[1]);

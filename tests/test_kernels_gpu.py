@@ -476,6 +476,27 @@ def test_attention_workgroup_width_does_not_change_the_bits(device, D, half_v):
         assert torch.equal(lse_small, lse_big[b:b + 1, :2, lo:hi])
 
 
+@pytest.mark.parametrize("half_v", [True, False])
+@pytest.mark.parametrize("S", [1000, 64, 65, 191])
+def test_two_phase_attention_kernel_gives_the_same_bits(device, S, half_v, monkeypatch):
+    """The experimental two-phase kernel (MI355_ATTN_PINGPONG=1; slower, kept as a measured
+    result) does the shipped kernel's arithmetic in the shipped order: same output and LSE bits,
+    ragged last tile, one-tile and two-tile sequences included."""
+    B, H, D = 2, 3, 128
+    gen = torch.Generator(device=device).manual_seed(29)
+    q, k, v = ((torch.randn(B, S, H, D, generator=gen, device=device) * 1.3).bfloat16()
+               for _ in range(3))
+    vv = v.to(torch.float16) if half_v else v
+    out, lse = torch.empty_like(q), torch.empty(B, H, S, dtype=torch.float32, device=device)
+    _C.flash_attn_fwd(q, k, vv, out, lse, D ** -0.5, v_is_f16=half_v)
+    monkeypatch.setenv("MI355_ATTN_PINGPONG", "1")
+    out2, lse2 = torch.empty_like(q), torch.empty_like(lse)
+    _C.flash_attn_fwd(q, k, vv, out2, lse2, D ** -0.5, v_is_f16=half_v)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    assert torch.equal(lse, lse2)
+
+
 def test_attention_at_video_length(device):
     """One sequence-parallel rank's attention of the HunyuanVideo configuration (3 of 24 heads
     over 118 800 image + 256 text tokens): the merge property over a ragged key split, and
