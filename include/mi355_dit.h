@@ -45,7 +45,8 @@ const char* mi355_last_error(void);
  * 7: mi355_f16_range_status was added (every bf16 -> half conversion is range-checked).
  * 8: mi355_guidance_rescale_static was added.
  * 9: mi355_linear_args gained w_shuffled; mi355_linear_grouped, mi355_shuffle_weight and
- *    mi355_shuffled_weight_bytes were added. */
+ *    mi355_shuffled_weight_bytes were added.
+ * 10: mi355_linear_args gained out_f16. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -88,9 +89,10 @@ int mi355_per_tensor_quant_fp8(const void* x, int64_t numel, void* q, float* s,
  * a: fp8 row-major, row stride lda.  b: fp8 COLUMN-major [K,N], i.e. the
  * weight W[N,K] with row stride ldb.  sa fp32 [M], sb fp32 [N], bias bf16 [N]
  * or NULL.  K % 128 == 0, lda/ldb % 16 == 0, N % 8 == 0, ldo % 8 == 0.
- * Restriction against the reference op: out_dtype is bf16 only.  The reference also builds
- * the fp16 epilogue (sgl-kernel/tests/test_fp8_gemm.py:17-35 runs both); the DiT path is bf16
- * throughout, so the registry wrapper raises for any other out_dtype instead of converting. */
+ * out_dtype: this entry point writes bf16 (the DiT path).  The reference op also takes
+ * float16 (sgl-kernel/tests/test_fp8_gemm.py:17-35 runs both): that is mi355_linear_ex with
+ * fp8 = 1 and out_f16 = 1 (same operands, half bias), which the registry wrapper calls for
+ * out_dtype == float16; other dtypes raise, as in the reference (fp8_gemm_kernel.cu:1477). */
 int mi355_fp8_scaled_mm(const void* a, const void* b, const float* sa, const float* sb,
                         const void* bias, void* out, int64_t M, int64_t N, int64_t K,
                         int64_t lda, int64_t ldb, int64_t ldo, void* stream);
@@ -175,6 +177,12 @@ typedef struct {
    * LDS-staged weight on every Flux shape, so the path is taken only when the environment
    * variable MI355_GEMM_WDIRECT is set (A/B timing); otherwise the field is ignored. */
   const void* w_shuffled;
+  /* Nonzero: out (and bias) are IEEE half instead of bf16 -- out_dtype = float16 of
+   * fp8_scaled_mm / fp8_blockwise_scaled_mm (the reference's kernel test runs both dtypes,
+   * sgl-kernel/tests/test_fp8_gemm.py:17-35).  fp32 accumulator x scales (+ bias) rounded once to
+   * half (block scales: product rounded to half, then the half bias added).  fp8 modes only, no
+   * activation / gate / residual / half-column range; the DiT itself is bf16 and never sets it. */
+  int out_f16;
 } mi355_linear_args;
 int mi355_linear_ex(const mi355_linear_args* args, void* stream);
 

@@ -52,6 +52,7 @@ struct GemmParams {
   // weight in MFMA-fragment order (mi355_shuffle_weight) and its k-steps per 32-row block
   const unsigned char* wsh;
   int wsh_ksteps;
+  int out_f16;  // host side only: picks the instantiation whose output and bias are IEEE half
 };
 
 // Up to two problems of one dtype walked by ONE persistent grid: the text-stream GEMM of a
@@ -72,7 +73,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // back row-major, 16 B per lane, applies gate/residual and stores 128 contiguous bytes per
 // row.  LDS operations of one wave execute in order, so the rounds need no barrier.
 // sb_l / sa_l / bias_l: the tile's per-channel scales, per-token scales and bias in LDS.
-template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE>
+// OUT16: the whole output (and the bias) is IEEE half, rounded once from fp32 -- out_dtype
+// float16 of the reference's fp8 GEMM ops; no gate / residual / half-column range in that mode.
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE, bool OUT16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM],
                                               unsigned char* scratch, const float* sb_l,
                                               const float* sa_l, const unsigned short* bias_l,
@@ -105,9 +108,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           f32x4 sbv = f32x4{1.f, 1.f, 1.f, 1.f};
           if constexpr (DT == 1 && !BLOCKSCALE) sbv = *reinterpret_cast<const f32x4*>(sb_l + nl);
           const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
-          const f32x4 bsv =
-              f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
-                    __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+          f32x4 bsv;
+          if constexpr (OUT16) {
+            auto hf = [](unsigned int bits) {
+              return (float)__builtin_bit_cast(_Float16, (unsigned short)bits);
+            };
+            bsv = f32x4{hf(bb[0] & 0xffffu), hf(bb[0] >> 16), hf(bb[1] & 0xffffu), hf(bb[1] >> 16)};
+          } else {
+            bsv = f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                        __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+          }
           float y[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -115,7 +125,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             if constexpr (DT == 1 && !BLOCKSCALE) v = v * sam * sbv[e];
             // the block-scaled linear casts the product to bf16 and THEN adds the bias
             // (python/sglang/srt/layers/quantization/fp8_utils.py:546-548)
-            if constexpr (BLOCKSCALE) v = rbf(v);
+            if constexpr (BLOCKSCALE && !OUT16) v = rbf(v);
+            if constexpr (BLOCKSCALE && OUT16) v = (float)(_Float16)v;
             v += bsv[e];
             y[e] = v;
           }
@@ -127,7 +138,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             y[2] = g1[0];
             y[3] = g1[1];
           }
-          if (as_f16) {
+          if constexpr (OUT16) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            pk[g][0] = __builtin_bit_cast(unsigned int, h2{(_Float16)y[0], (_Float16)y[1]});
+            pk[g][1] = __builtin_bit_cast(unsigned int, h2{(_Float16)y[2], (_Float16)y[3]});
+          } else if (as_f16) {
             pk[g][0] = pack_bf2_as_f16(y[0], y[1]);
             pk[g][1] = pack_bf2_as_f16(y[2], y[3]);
 #pragma unroll
@@ -137,7 +152,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             pk[g][1] = pack_bf2(y[2], y[3]);
           }
         }
-        if (as_f16) note_f16_block(p.f16_counters, group_max<64>(amax), lane);
+        if constexpr (!OUT16)
+          if (as_f16) note_f16_block(p.f16_counters, group_max<64>(amax), lane);
         // widen: lanes l and l+32 exchange so each owns 8 consecutive channels
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
@@ -189,7 +205,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // use last is idle: the first K tile of the NEXT output tile is sent there by LDS-DMA before
 // the epilogue starts and lands underneath it, and the stage used last becomes the
 // epilogue's scratch (one 4-KiB slice per wave) and table area.
-template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE>
+template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE,
+          bool OUT16 = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
@@ -491,7 +508,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
       load_tables(m0, n0);
     }
     __syncthreads();  // tables visible
-    gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE>(p, acc, area + wave * SCRATCH_WAVE, sb_l,
+    gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE, OUT16>(p, acc, area + wave * SCRATCH_WAVE, sb_l,
                                                             sa_l, bias_l, em0, en0, wave, lane);
     if (!more) break;
     vb = nvb;
@@ -838,7 +855,7 @@ int resident_workgroups(int lds_bytes) {
   return cus * per_cu;
 }
 
-template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS>
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS, bool OUT16 = false>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int LDS = 2 * (BM + BN) * 128;
@@ -849,7 +866,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
-  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS>;
+  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16>;
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -963,6 +980,11 @@ int build_params(const mi355_linear_args* a, GemmParams& p) {
   p.group = ((a->N + 255) / 256) <= 16 ? 2 : 8;
   p.wsh = (const unsigned char*)a->w_shuffled;
   p.wsh_ksteps = (int)(kbytes / (a->fp8 ? 64 : 32));
+  p.out_f16 = a->out_f16 ? 1 : 0;
+  MI355_REQUIRE(!a->out_f16 || (a->fp8 && !a->gate && !a->residual && a->act == MI355_ACT_NONE &&
+                                a->f16_begin == a->f16_end),
+                "linear: half output is built for the plain fp8 GEMMs (no activation, gate, residual "
+                "or half-column range)");
   return MI355_OK;
 }
 
@@ -1009,6 +1031,10 @@ int launch_wdirect(const GroupParams& gp, hipStream_t st) {
 }
 
 int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hipStream_t st) {
+  // half output is an interface-compatibility mode, not a hot path: one tile class serves it
+  if (p.out_f16)
+    return block_scale ? launch_gemm<1, 2, 2, 2, 2, true, true>(p, st)
+                       : launch_gemm<1, 2, 2, 2, 2, false, true>(p, st);
   if (block_scale)
     return big ? launch_gemm<1, 4, 2, 2, 4, true>(p, st) : launch_gemm<1, 2, 2, 2, 2, true>(p, st);
   if (fp8)

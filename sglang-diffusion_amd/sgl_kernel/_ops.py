@@ -80,7 +80,8 @@ def _check_mm(mat_a, mat_b, out_dtype, what):
     _require(mat_a.stride(1) == 1, f"{what}: mat_a must be row major")
     _require(mat_b.stride(0) == 1, f"{what}: mat_b must be column major (a [N,K] weight, transposed)")
     _require(mat_a.shape[1] == mat_b.shape[0], f"{what}: inner dimensions differ")
-    _require(out_dtype == torch.bfloat16, f"{what}: out_dtype must be bfloat16 on this build")
+    _require(out_dtype in (torch.bfloat16, torch.float16),
+             f"{what}: out_dtype must be bfloat16 or float16")
     _require(mat_a.shape[1] % 16 == 0, f"{what}: K must be a multiple of 16")
     _require(mat_b.shape[1] % 8 == 0, f"{what}: N must be a multiple of 8")
 

@@ -59,6 +59,7 @@ class LinearArgs(ctypes.Structure):
         ("sb_sk", _i64),
         ("sb_sn", _i64),
         ("w_shuffled", _ptr),
+        ("out_f16", _int),
     ]
 
 
@@ -148,7 +149,7 @@ _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def load_library() -> ctypes.CDLL:
@@ -242,9 +243,14 @@ def per_tensor_quant_fp8(x, q, s, is_static: bool) -> None:
 
 # ---------------------------------------------------------------------- GEMM --
 def fp8_scaled_mm(a, w, sa, sb, bias, out) -> None:
-    """a [M,K] fp8, w [N,K] fp8 (K contiguous), sa [M], sb [N] fp32, out [M,N] bf16."""
+    """a [M,K] fp8, w [N,K] fp8 (K contiguous), sa [M], sb [N] fp32, out [M,N] bf16 -- or
+    float16, then with a float16 bias."""
     M, K = a.shape
     N = w.shape[0]
+    if out.dtype == torch.float16:
+        linear_ex(a, w, out, M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0), ldo=out.stride(0),
+                  sa=sa, sb=sb, bias=bias, fp8=True, out_f16=True)
+        return
     _check(
         load_library().mi355_fp8_scaled_mm(
             a.data_ptr(), w.data_ptr(), sa.data_ptr(), sb.data_ptr(), _p(bias), out.data_ptr(),
@@ -257,6 +263,15 @@ def fp8_scaled_mm(a, w, sa, sb, bias, out) -> None:
 def fp8_blockwise_scaled_mm(a, w, sa, sb, out, sa_strides, sb_strides) -> None:
     M, K = a.shape
     N = w.shape[0]
+    if out.dtype == torch.float16:
+        args = _linear_args(a, w, out, M=M, N=N, K=K, lda=a.stride(0), ldw=w.stride(0),
+                            ldo=out.stride(0), sa=sa, sb=sb, fp8=True, out_f16=True)
+        args.block_scale = 1
+        args.sa_sm, args.sa_sk = sa_strides
+        args.sb_sk, args.sb_sn = sb_strides
+        _check(load_library().mi355_linear_ex(ctypes.byref(args), _stream(a)),
+               "fp8_blockwise_scaled_mm")
+        return
     _check(
         load_library().mi355_fp8_blockwise_scaled_mm(
             a.data_ptr(), w.data_ptr(), sa.data_ptr(), sb.data_ptr(), out.data_ptr(),
@@ -282,7 +297,7 @@ def linear_bf16(x, w, bias, out, act: int = 0) -> None:
 def _linear_args(
     a, w, out, *, M, N, K, lda, ldw, ldo, sa=None, sb=None, bias=None, residual=None, gate=None,
     ldg=0, gate_rows=0, a_map=None, o_map=None, fp8=False, act=0, f16_cols=None,
-    block_scale=False, w_shuffled=None, into: Optional[LinearArgs] = None,
+    block_scale=False, w_shuffled=None, out_f16=False, into: Optional[LinearArgs] = None,
 ) -> LinearArgs:
     args = LinearArgs() if into is None else into
     args.a, args.w, args.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -302,6 +317,7 @@ def _linear_args(
         args.sa_sm, args.sa_sk = sa.stride(0), sa.stride(1)
         args.sb_sn, args.sb_sk = sb.stride(0), sb.stride(1)
     args.w_shuffled = _p(w_shuffled)
+    args.out_f16 = int(bool(out_f16))
     return args
 
 

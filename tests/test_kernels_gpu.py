@@ -118,6 +118,41 @@ def test_fp8_scaled_mm_vs_oracle(device, M, N, K, bias):
     _gemm_close(out, ref)
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(1, 16, 512, True), (128, 512, 1024, False),
+                                         (1024, 1024, 2048, True), (300, 136, 16384, True)])
+def test_fp8_scaled_mm_float16_output(device, M, N, K, bias):
+    """out_dtype = float16 through the op registry, inputs and formula of
+    sgl-kernel/tests/test_fp8_gemm.py:6-35 (full +-448 range, scales ~1e-3): the fp32 accumulator
+    times the scales, plus the half bias, rounded to half.  Checked to the reference test's own
+    rtol 0.02 / atol 1 and, tighter, to 1e-3 relative against the same formula in float64."""
+    import sgl_kernel  # noqa: F401  (registers torch.ops.sgl_kernel)
+
+    a = ((torch.rand(M, K, generator=g(41)) - 0.5) * 2 * 448).to(FP8)
+    w = ((torch.rand(N, K, generator=g(42)) - 0.5) * 2 * 448).to(FP8)
+    sa = torch.randn(M, generator=g(43)) * 0.001
+    sb = torch.randn(N, generator=g(44)) * 0.001
+    b = torch.randn(N, generator=g(45)).half() if bias else None
+    ref = (a.double() @ w.double().t()) * sa.double().view(-1, 1) * sb.double().view(1, -1)
+    if bias:
+        ref = ref + b.double().view(1, -1)
+    out = torch.ops.sgl_kernel.fp8_scaled_mm(a.to(device), w.to(device).t(), sa.to(device),
+                                             sb.to(device), torch.float16,
+                                             b.to(device) if bias else None)
+    assert out.dtype == torch.float16 and tuple(out.shape) == (M, N)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=0.02, atol=1)
+    assert rel_l2(out.cpu().float(), ref.float()) <= 1e-3
+    # block-scaled op, same dtype
+    if K % 128 == 0 and N % 128 == 0 and not bias:
+        x = torch.randn(M, K, generator=g(46)).bfloat16()
+        wq, ws = ops.quantize_weight_block((torch.randn(N, K, generator=g(47)) * 0.2).bfloat16())
+        xq, xs = ops.per_token_group_quant_fp8(x, 128)
+        refb = ops.fp8_blockwise_scaled_mm(xq, wq, xs, ws)       # bf16-rounded oracle
+        outb = torch.ops.sgl_kernel.fp8_blockwise_scaled_mm(
+            xq.to(device), wq.to(device).t(), xs.to(device), ws.to(device).t(), torch.float16)
+        assert outb.dtype == torch.float16
+        assert rel_l2(outb.cpu().float(), refb.float()) <= 3e-3   # the oracle's own bf16 rounding
+
+
 def test_fp8_scaled_mm_exact_on_integer_data(device):
     """Small integers: every product and partial sum is exact, so any operand-layout or
     indexing slip shows as a hard mismatch.  Asymmetric operands catch transposes."""
