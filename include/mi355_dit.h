@@ -46,7 +46,8 @@ const char* mi355_last_error(void);
  * 8: mi355_guidance_rescale_static was added.
  * 9: mi355_linear_args gained w_shuffled; mi355_linear_grouped, mi355_shuffle_weight and
  *    mi355_shuffled_weight_bytes were added.
- * 10: mi355_linear_args gained out_f16. */
+ * 10: mi355_linear_args gained out_f16.
+ * 11: mi355_linear_args gained kn_weight, kn_cos, kn_sin, kn_eps, kn_seq, kn_begin, kn_end. */
 int mi355_abi_version(void);
 
 /* ---------------------------------------------------------------- quant --
@@ -183,6 +184,22 @@ typedef struct {
    * half (block scales: product rounded to half, then the half bias added).  fp8 modes only, no
    * activation / gate / residual / half-column range; the DiT itself is bf16 and never sets it. */
   int out_f16;
+  /* Optional (kn_weight != NULL): output columns [kn_begin, kn_end), heads of 128 channels, get
+   * the per-head RMSNorm (fp32 weight[128], eps) and -- with kn_cos / kn_sin fp32 [kn_seq, 64] --
+   * the interleaved rotary embedding of row (mapped output row) % kn_seq before they are stored:
+   * apply_qk_norm + apply_flashinfer_rope_qk_inplace on the key third of a fused q|k|v projection
+   * (runtime/models/dits/flux.py:356-393) without a pass of their own.  Bit-identical to this
+   * call without the fields followed by mi355_qk_norm_rope(q = NULL, k, ...) on those columns.
+   * bf16 or per-token fp8 mode, no activation / gate / residual / block scales, M > 16; the
+   * 256 x 256 tile class is used whatever the shape (a wave must hold a whole head).
+   * Measured on the Flux shapes: the separate pass costs 46.6 us, the same work in the
+   * projection's (exposed) epilogue adds about 90 us to it -- callers that can afford the
+   * separate pass should keep it; the fields serve callers that cannot launch one. */
+  const float* kn_weight;
+  const float* kn_cos;
+  const float* kn_sin;
+  float kn_eps;
+  int64_t kn_seq, kn_begin, kn_end;
 } mi355_linear_args;
 int mi355_linear_ex(const mi355_linear_args* args, void* stream);
 

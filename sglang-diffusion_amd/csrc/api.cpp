@@ -15,4 +15,4 @@ void mi355_set_error(const char* fmt, ...) {
 
 extern "C" const char* mi355_last_error(void) { return g_last_error; }
 
-extern "C" int mi355_abi_version(void) { return 10; }
+extern "C" int mi355_abi_version(void) { return 11; }

@@ -53,6 +53,12 @@ struct GemmParams {
   const unsigned char* wsh;
   int wsh_ksteps;
   int out_f16;  // host side only: picks the instantiation whose output and bias are IEEE half
+  // per-head RMSNorm + interleaved rotation of output columns [kn_begin, kn_end) in the epilogue
+  const float* kn_w;
+  const float* kn_cos;
+  const float* kn_sin;
+  float kn_eps;
+  int kn_seq, kn_begin, kn_end;
 };
 
 // Up to two problems of one dtype walked by ONE persistent grid: the text-stream GEMM of a
@@ -75,7 +81,14 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // sb_l / sa_l / bias_l: the tile's per-channel scales, per-token scales and bias in LDS.
 // OUT16: the whole output (and the bias) is IEEE half, rounded once from fp32 -- out_dtype
 // float16 of the reference's fp8 GEMM ops; no gate / residual / half-column range in that mode.
-template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE, bool OUT16 = false>
+// KNORM: output columns [kn_begin, kn_end) are heads of 128 channels that get the per-head
+// RMSNorm and the interleaved rotary embedding of qk_norm_rope_kernel (elementwise.hip) before
+// they are stored -- the key third of a fused q|k|v projection.  A wave's TN * 32 = 128 columns
+// are exactly one head and a lane holds 64 channels of ONE row (the other 64 sit in the lane 32
+// away), so the row statistic is an in-lane sum plus two exchanges.  Same arithmetic in the
+// same order as the stand-alone kernel on the stored bf16 values, so both give the same bits.
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE, bool OUT16 = false,
+          bool KNORM = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM],
                                               unsigned char* scratch, const float* sb_l,
                                               const float* sa_l, const unsigned short* bias_l,
@@ -91,6 +104,98 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     float sam = 1.f;
     if constexpr (DT == 1 && !BLOCKSCALE) sam = sa_l[wm * TM * 32 + j * 32 + r];
     const int mw = m0 + wm * TM * 32 + j * 32;
+    bool normed = false;  // wave-uniform: this wave's head was finished in place below
+    if constexpr (KNORM) {
+      static_assert(TN == 4 && !BLOCKSCALE && !OUT16, "one head of 128 channels per wave");
+      const int head0 = n0 + wn * TN * 32;
+      if (head0 >= p.kn_begin && head0 < p.kn_end) {
+        normed = true;
+        // (1) the linear's bf16 result, in place, exactly as the plain path below forms it
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int i = c >> 2, g = c & 3;
+          const int nl = wn * TN * 32 + i * 32 + 8 * g + 4 * h;
+          f32x4 sbv = f32x4{1.f, 1.f, 1.f, 1.f};
+          if constexpr (DT == 1) sbv = *reinterpret_cast<const f32x4*>(sb_l + nl);
+          const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
+          const f32x4 bsv =
+              f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                    __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][4 * g + e];
+            if constexpr (DT == 1) v = fmaf(v * sam, sbv[e], bsv[e]);  // as the plain path
+            else v += bsv[e];
+            acc[i][j][4 * g + e] = rbf(v);
+          }
+        }
+        // (2) sum of squares of the row: chunk c = channels 8c .. 8c+7 is summed element by
+        // element (this lane's four, continued by the partner's four), the 16 chunk sums by a
+        // butterfly over chunk-index bits 3, 2, 1, 0 -- the order of group_sum<16> over the 16
+        // lanes that hold one row in qk_norm_rope_kernel
+        auto partner = [&](float x) {
+          const unsigned int xb = __float_as_uint(x);
+          auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+          return __uint_as_float(h ? sw[0] : sw[1]);
+        };
+        float cs[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int i = c >> 2, g = c & 3;
+          float sq = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sq += acc[i][j][4 * g + e] * acc[i][j][4 * g + e];
+          // lanes h = 1 continue the chain the partner (elements 0..3 of the chunk) began
+          float sq2 = partner(sq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sq2 += acc[i][j][4 * g + e] * acc[i][j][4 * g + e];
+          cs[c] = sq2;  // the chunk's sum in lanes h = 1
+        }
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+          for (int c = 0; c < w; ++c) cs[c] = cs[c] + cs[c + w];
+        // (the exchange is its own statement: inside the ?: it would run with half the wave
+        // masked off and fetch nothing)
+        const float tot_partner = partner(cs[0]);
+        const float tot = h ? cs[0] : tot_partner;
+        const float rs = rsqrtf(tot / 128.0f + p.kn_eps);
+        // (3) weight, rounding, rotation
+        const int m = min(mw + r, p.M - 1);
+        const int64_t orow =
+            map_row32(m, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset);
+        const unsigned pos = (unsigned)orow % (unsigned)p.kn_seq;
+        const float* cosr = p.kn_cos ? p.kn_cos + (int64_t)pos * 64 : nullptr;
+        const float* sinr = p.kn_cos ? p.kn_sin + (int64_t)pos * 64 : nullptr;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const int i = c >> 2, g = c & 3;
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(p.kn_w + 8 * c + 4 * h);
+          float f[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = rbf((acc[i][j][4 * g + e] * rs) * wv[e]);
+          if (cosr) {
+            const f32x2 cc = *reinterpret_cast<const f32x2*>(cosr + 4 * c + 2 * h);
+            const f32x2 sn = *reinterpret_cast<const f32x2*>(sinr + 4 * c + 2 * h);
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+              const float x1 = f[2 * q2], x2 = f[2 * q2 + 1];
+              f[2 * q2] = fmaf(-x2, sn[q2], __fmul_rn(x1, cc[q2]));
+              f[2 * q2 + 1] = fmaf(x1, sn[q2], __fmul_rn(x2, cc[q2]));
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = f[e];
+        }
+#ifdef KN_DEBUG_TOT
+        {
+          const unsigned int tb = __float_as_uint(tot);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[0][j][e] = (float)((tb >> (8 * e)) & 0xffu);
+        }
+#endif
+      }
+    }
 #pragma unroll
     for (int ip = 0; ip < TN / 2; ++ip) {
 #pragma unroll
@@ -109,6 +214,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           if constexpr (DT == 1 && !BLOCKSCALE) sbv = *reinterpret_cast<const f32x4*>(sb_l + nl);
           const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
           f32x4 bsv;
+          if constexpr (KNORM) {
+            // a head finished above passes through: x * 1 * 1 + (-0) == x, zeros keep their sign
+            if (normed) sbv = f32x4{1.f, 1.f, 1.f, 1.f};
+          }
           if constexpr (OUT16) {
             auto hf = [](unsigned int bits) {
               return (float)__builtin_bit_cast(_Float16, (unsigned short)bits);
@@ -122,12 +231,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[i][j][4 * g + e];
-            if constexpr (DT == 1 && !BLOCKSCALE) v = v * sam * sbv[e];
             // the block-scaled linear casts the product to bf16 and THEN adds the bias
             // (python/sglang/srt/layers/quantization/fp8_utils.py:546-548)
             if constexpr (BLOCKSCALE && !OUT16) v = rbf(v);
             if constexpr (BLOCKSCALE && OUT16) v = (float)(_Float16)v;
-            v += bsv[e];
+            const float be = (KNORM && normed) ? -0.0f : bsv[e];
+            // per-token x per-channel scales and the bias: one multiply, one fused multiply-add
+            // (spelled out: the key-norm pass above must form the very same value)
+            if constexpr (DT == 1 && !BLOCKSCALE)
+              v = fmaf(v * ((KNORM && normed) ? 1.f : sam), sbv[e], be);
+            else
+              v += be;
             y[e] = v;
           }
           if (p.act == MI355_ACT_GELU_TANH) {
@@ -206,7 +320,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // the epilogue starts and lands underneath it, and the stage used last becomes the
 // epilogue's scratch (one 4-KiB slice per wave) and table area.
 template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE,
-          bool OUT16 = false>
+          bool OUT16 = false, bool KNORM = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
@@ -508,7 +622,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
       load_tables(m0, n0);
     }
     __syncthreads();  // tables visible
-    gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE, OUT16>(p, acc, area + wave * SCRATCH_WAVE, sb_l,
+    gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE, OUT16, KNORM>(p, acc, area + wave * SCRATCH_WAVE, sb_l,
                                                             sa_l, bias_l, em0, en0, wave, lane);
     if (!more) break;
     vb = nvb;
@@ -855,7 +969,8 @@ int resident_workgroups(int lds_bytes) {
   return cus * per_cu;
 }
 
-template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS, bool OUT16 = false>
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS, bool OUT16 = false,
+          bool KNORM = false>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int LDS = 2 * (BM + BN) * 128;
@@ -866,7 +981,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
-  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16>;
+  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16, KNORM>;
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -981,6 +1096,30 @@ int build_params(const mi355_linear_args* a, GemmParams& p) {
   p.wsh = (const unsigned char*)a->w_shuffled;
   p.wsh_ksteps = (int)(kbytes / (a->fp8 ? 64 : 32));
   p.out_f16 = a->out_f16 ? 1 : 0;
+  p.kn_w = a->kn_weight;
+  p.kn_cos = a->kn_cos;
+  p.kn_sin = a->kn_sin;
+  p.kn_eps = a->kn_eps;
+  p.kn_seq = (int)a->kn_seq;
+  p.kn_begin = (int)a->kn_begin;
+  p.kn_end = (int)a->kn_end;
+  if (a->kn_weight) {
+    MI355_REQUIRE(!a->block_scale && !a->out_f16 && !a->gate && !a->residual &&
+                      a->act == MI355_ACT_NONE && a->M > 16,
+                  "linear: the fused key norm is built for the plain bf16 / per-token fp8 projection");
+    MI355_REQUIRE(a->kn_begin >= 0 && a->kn_begin % 128 == 0 && a->kn_end % 128 == 0 &&
+                      a->kn_end >= a->kn_begin && a->kn_end <= a->N,
+                  "linear: kn_begin/kn_end must be multiples of the head size 128 inside [0, N]");
+    MI355_REQUIRE((a->kn_cos == nullptr) == (a->kn_sin == nullptr) && a->kn_seq > 0 &&
+                      a->kn_seq < (1ll << 31),
+                  "linear: kn_cos / kn_sin come in pairs, kn_seq must be positive");
+    MI355_REQUIRE(((uintptr_t)a->kn_weight % 16) == 0 && ((uintptr_t)a->kn_cos % 8) == 0 &&
+                      ((uintptr_t)a->kn_sin % 8) == 0,
+                  "linear: kn_weight must be 16-byte, kn_cos / kn_sin 8-byte aligned");
+    // a half-column range may not overlap the normed heads
+    MI355_REQUIRE(a->f16_end <= a->kn_begin || a->f16_begin >= a->kn_end || a->f16_begin == a->f16_end,
+                  "linear: half columns and normed columns overlap");
+  }
   MI355_REQUIRE(!a->out_f16 || (a->fp8 && !a->gate && !a->residual && a->act == MI355_ACT_NONE &&
                                 a->f16_begin == a->f16_end),
                 "linear: half output is built for the plain fp8 GEMMs (no activation, gate, residual "
@@ -1035,6 +1174,10 @@ int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hip
   if (p.out_f16)
     return block_scale ? launch_gemm<1, 2, 2, 2, 2, true, true>(p, st)
                        : launch_gemm<1, 2, 2, 2, 2, false, true>(p, st);
+  // the key-side norm + rotation needs a whole head per wave: the 256 x 256 class only
+  if (p.kn_w)
+    return fp8 ? launch_gemm<1, 4, 2, 2, 4, false, false, true>(p, st)
+               : launch_gemm<0, 4, 2, 2, 4, false, false, true>(p, st);
   if (block_scale)
     return big ? launch_gemm<1, 4, 2, 2, 4, true>(p, st) : launch_gemm<1, 2, 2, 2, 2, true>(p, st);
   if (fp8)

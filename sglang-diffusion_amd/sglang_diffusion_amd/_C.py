@@ -60,6 +60,13 @@ class LinearArgs(ctypes.Structure):
         ("sb_sn", _i64),
         ("w_shuffled", _ptr),
         ("out_f16", _int),
+        ("kn_weight", _ptr),
+        ("kn_cos", _ptr),
+        ("kn_sin", _ptr),
+        ("kn_eps", _f32),
+        ("kn_seq", _i64),
+        ("kn_begin", _i64),
+        ("kn_end", _i64),
     ]
 
 
@@ -149,7 +156,7 @@ _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 def load_library() -> ctypes.CDLL:
@@ -297,7 +304,8 @@ def linear_bf16(x, w, bias, out, act: int = 0) -> None:
 def _linear_args(
     a, w, out, *, M, N, K, lda, ldw, ldo, sa=None, sb=None, bias=None, residual=None, gate=None,
     ldg=0, gate_rows=0, a_map=None, o_map=None, fp8=False, act=0, f16_cols=None,
-    block_scale=False, w_shuffled=None, out_f16=False, into: Optional[LinearArgs] = None,
+    block_scale=False, w_shuffled=None, out_f16=False, k_norm=None,
+    into: Optional[LinearArgs] = None,
 ) -> LinearArgs:
     args = LinearArgs() if into is None else into
     args.a, args.w, args.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -318,6 +326,14 @@ def _linear_args(
         args.sb_sn, args.sb_sk = sb.stride(0), sb.stride(1)
     args.w_shuffled = _p(w_shuffled)
     args.out_f16 = int(bool(out_f16))
+    if k_norm is not None:
+        # (weight fp32 [128], eps, cos, sin fp32 [seq, 64] or None, seq, (col_begin, col_end))
+        kw_, eps, kcos, ksin, seq, cols = k_norm
+        args.kn_weight, args.kn_cos, args.kn_sin = kw_.data_ptr(), _p(kcos), _p(ksin)
+        args.kn_eps, args.kn_seq = float(eps), int(seq)
+        args.kn_begin, args.kn_end = cols
+    else:
+        args.kn_weight = None
     return args
 
 

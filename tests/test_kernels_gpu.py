@@ -906,3 +906,50 @@ def test_grouped_linear_equals_two_launches(device, fp8, monkeypatch):
     _C.linear_ex(x, w, r1, **kw)
     _C.linear_ex(xq, wq, r2, **dict(kw, fp8=True, sa=s1, sb=s2))
     assert torch.equal(o1, r1) and torch.equal(o2, r2)
+
+
+@pytest.mark.parametrize("fp8", [True, False])
+@pytest.mark.parametrize("M,rows_per_batch,seq,off", [(640, 0, 320, 0), (300, 100, 164, 64),
+                                                       (257, 0, 4608, 0)])
+def test_linear_ex_fused_key_norm_equals_the_separate_pass(device, fp8, M, rows_per_batch, seq, off):
+    """q|k|v projection with the key heads normed and rotated in the epilogue == the same
+    projection followed by qk_norm_rope(q=None, k) on those columns, bit for bit: ragged M, an
+    output row map (the image rows of a joint buffer), V columns in half beside it."""
+    H, D, K = 3, 128, 256
+    N = 3 * H * D
+    gen = torch.Generator(device=device).manual_seed(31)
+    x = torch.randn(M, K, generator=gen, device=device).bfloat16()
+    w = (torch.randn(N, K, generator=gen, device=device) * K ** -0.5).bfloat16()
+    b = (torch.randn(N, generator=gen, device=device) * 0.1).bfloat16()
+    nw = (1.0 + 0.1 * torch.randn(D, generator=gen, device=device)).float()
+    ang = torch.rand(seq, D // 2, generator=gen, device=device) * 6.28
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    if rows_per_batch:
+        nb = M // rows_per_batch
+        o_map, rows_out = (rows_per_batch, seq, off), nb * seq
+    else:
+        nb, o_map, rows_out = M // seq if M % seq == 0 else 1, None, M
+    if fp8:
+        xq = torch.empty(M, K, dtype=FP8, device=device)
+        xs = torch.empty(M, dtype=torch.float32, device=device)
+        _C.per_token_quant_fp8(x, xq, xs)
+        wq, wsc = ops.quantize_weight_per_channel(w.cpu())
+        a_in, w_in, kw = xq, wq.to(device), dict(sa=xs, sb=wsc.to(device).float().contiguous(), fp8=True)
+    else:
+        a_in, w_in, kw = x, w, dict(fp8=False)
+    common = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, bias=b, o_map=o_map,
+                  f16_cols=(2 * H * D, 3 * H * D), **kw)
+    ref = torch.zeros(rows_out, N, dtype=torch.bfloat16, device=device)
+    _C.linear_ex(a_in, w_in, ref, **common)
+    fused = torch.zeros_like(ref)
+    _C.linear_ex(a_in, w_in, fused, k_norm=(nw, 1e-6, cos, sin, seq, (H * D, 2 * H * D)), **common)
+    # the separate pass on the rows the projection wrote
+    if rows_per_batch:
+        k_view = ref.view(nb, seq, 3, H, D)[:, off:off + rows_per_batch, 1]
+        _C.qk_norm_rope(None, k_view, nw, nw, nw, nw, 0, 1e-6, cos[off:], sin[off:], True)
+    elif M % seq == 0:
+        _C.qk_norm_rope(None, ref.view(nb, seq, 3, H, D)[:, :, 1], nw, nw, nw, nw, 0, 1e-6, cos, sin, True)
+    else:
+        _C.qk_norm_rope(None, ref.view(1, M, 3, H, D)[:, :, 1], nw, nw, nw, nw, 0, 1e-6, cos, sin, True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(torch.int16), ref.view(torch.int16))
