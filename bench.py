@@ -344,10 +344,12 @@ def main():
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": None,
-                "kernel": {"fp8": "gemm_kernel<1,4,2,2,4,false> (fp8 W8A8 linear, 256x256x128B tile)",
-                           "bf16": "gemm_kernel<0,4,2,2,4,false> (bf16 linear, 256x256x128B tile)",
-                           "fp8-block": "gemm_kernel<1,4,2,2,4,true> (block-scaled fp8 linear, "
-                                        "256x256x128B tile)"}[args.mode],
+                "kernel": {"fp8": "gemm_kernel<1,4,2,2,4,false,false,false> (fp8 W8A8 linear, "
+                                  "256x256x128B tile)",
+                           "bf16": "gemm_kernel<0,4,2,2,4,false,false,false> (bf16 linear, "
+                                   "256x256x128B tile)",
+                           "fp8-block": "gemm_kernel<1,4,2,2,4,true,false,false> (block-scaled fp8 "
+                                        "linear, 256x256x128B tile)"}[args.mode],
                 "launches_per_step": d["n"] // nsteps_traced,
                 "avg_launch_us": d["ms"] * 1e3 / d["n"],
                 "flop_per_launch": d["flops"] / d["n"]}
@@ -357,9 +359,13 @@ def main():
         import glob
 
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-        key = {"fp8": "gemm_kernel<1, 4, 2, 2, 4, false>", "bf16": "gemm_kernel<0, 4, 2, 2, 4, false>",
-               "fp8-block": "gemm_kernel<1, 4, 2, 2, 4, true>"}[args.mode]
-        roofline["traffic"] = json.load(open(pmc))["kernels"][key]["traffic_bytes_per_launch"]
+        # the profiler prints every template argument: <dtype, waves m, waves n, tm, tn, block
+        # scales, half output, fused key norm>; older summaries have the first six only
+        key = {"fp8": "gemm_kernel<1, 4, 2, 2, 4, false", "bf16": "gemm_kernel<0, 4, 2, 2, 4, false",
+               "fp8-block": "gemm_kernel<1, 4, 2, 2, 4, true"}[args.mode]
+        kernels = json.load(open(pmc))["kernels"]
+        name = next(k for k in (key + ">", key + ", false, false>") if k in kernels)
+        roofline["traffic"] = kernels[name]["traffic_bytes_per_launch"]
         roofline["traffic_unit"] = "bytes per launch at the L2 memory side (2*FETCH_SIZE + WRITE_SIZE)"
         roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
         roofline["algorithmic_bytes_per_launch"] = d["bytes"] / d["n"]
