@@ -180,10 +180,11 @@ class FluxEngine:
         self._ws: Dict[Tuple, dict] = {}
         # optional per-launch timing: list of (kind, flops, bytes, start_event, end_event)
         self.trace: Optional[list] = None
-        # run the double blocks' text chain on a second stream (same bits; measured -1.1 % per
-        # step at B = 4).  Off by default: per-launch timing is only meaningful one stream at a
-        # time, and tracing falls back to one stream anyway.
-        self.overlap_text = os.environ.get("MI355_FLUX_OVERLAP_TEXT", "0") == "1"
+        # run the double blocks' text chain on a second stream: same bits, capturable in a HIP
+        # graph, -2 ms (-1 %) per step at B = 4 in same-box A/Bs.  Per-launch timing (self.trace)
+        # and probes fall back to one stream, where a launch's events mean something.
+        # MI355_FLUX_OVERLAP_TEXT=0 turns it off.
+        self.overlap_text = os.environ.get("MI355_FLUX_OVERLAP_TEXT", "1") == "1"
         # key-side RMSNorm + rotation in the q|k|v projection's epilogue instead of its own pass:
         # same bits, but measured SLOWER (the pass costs 2.65 ms per step, the epilogue work --
         # exposed, two waves per SIMD, a gather of the rotation table -- adds 5.1 ms to the

@@ -213,6 +213,10 @@ def test_fused_step_replays_from_a_hip_graph(device, overlap):
     fd = (freqs[0].to(device), freqs[1].to(device))
     a = [x.to(device) for x in small_inputs(B, Ti, Tt, cfg, seed=1)]
     b = [x.to(device) for x in small_inputs(B, Ti, Tt, cfg, seed=2)]
+    from sglang_diffusion_amd.models.flux_engine import FluxEngine
+
+    model._engine = model._engine or FluxEngine(model)
+    model._engine.overlap_text = False
     with torch.no_grad():
         want_b = model.forward_fused(*b, fd).clone()        # also warms up: workspace, attributes
         if overlap:
