@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--no-c4", action="store_true",
                     help="skip the fixed-size 32-CFG-request job through the batch scheduler")
     ap.add_argument("--c4-requests", type=int, default=32)
+    ap.add_argument("--c4-timeout", type=float, default=600.0,
+                    help="seconds after which the line is printed without the c4 object")
     ap.add_argument("--c4-steps", type=int, default=None,
                     help="denoise steps per micro-batch of the c4 job (default: --steps)")
     ap.add_argument("--launch-check", action="store_true",
@@ -375,8 +377,8 @@ def main():
     fl = flux_step_flops(B, n_double=cfg.num_layers, n_single=cfg.num_single_layers)
 
     # ---- the fixed-size CFG job through the batch scheduler (strong scaling) -----------------
-    c4 = None
-    if not args.no_c4 and not args.schnell:
+    def run_c4():
+        c4 = None
         from sglang_diffusion_amd.runtime.batch_scheduler import DataParallelBatchScheduler
 
         n_req, c4_steps = args.c4_requests, args.c4_steps or args.steps
@@ -418,8 +420,16 @@ def main():
                   "images_per_s_note": (f"{n_req} images / (scatter + gather + compute x "
                                         f"{NUM_INFERENCE_STEPS}/{c4_steps}); each image costs 2 DiT "
                                         "samples per step, so x2 compares with `value`")}
+        return c4
 
+    want_c4 = not args.no_c4 and not args.schnell
     if rank != 0:
+        if want_c4:
+            try:
+                run_c4()
+            except Exception as e:  # rank 0 reports; a rank that cannot go on must not hang it
+                print(f"[rank {rank}] c4 workload failed: {type(e).__name__}: {e}", file=sys.stderr)
+                os._exit(1)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -453,11 +463,34 @@ def main():
         "mfma_utilisation_vs_fp8_peak": fl["total"] / step_s / 1e12 / PEAK_FP8_TFLOPS,  # per GPU
         "mixed_roofline_min_ms": (fl["fp8"] / (PEAK_FP8_TFLOPS * 1e12)
                                   + (fl["bf16"] + fl["attn"]) / (PEAK_BF16_TFLOPS * 1e12)) * 1e3,
-        "roofline": roofline, "breakdown": breakdown, "cpu_baseline": cpu, "c4": c4,
+        "roofline": roofline, "breakdown": breakdown, "cpu_baseline": cpu, "c4": None,
     }
-    print(json.dumps(out))
+    if want_c4:
+        # The headline line above is complete; the fixed-size CFG job adds to it.  Whatever
+        # happens in there (an exception here, a rank that died and left the others in a
+        # collective), the line is printed: a watchdog prints it without `c4` and ends the
+        # process if the job does not finish in time.
+        import threading
+
+        def give_up():
+            out["c4"] = {"error": f"the CFG job did not finish within {args.c4_timeout} s"}
+            print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.c4_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            out["c4"] = run_c4()
+        except Exception as e:
+            out["c4"] = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+    print(json.dumps(out), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -204,7 +204,8 @@ class DataParallelBatchScheduler:
         if self.queue_on_rank0:
             meta, mine = scatter_requests(
                 [r for _, r in self.waiting_queue] if self.rank == 0 else None,
-                lambda costs: assign_requests(costs, self.world_size), self.group)
+                lambda costs: assign_requests(costs, self.world_size), self.group,
+                device=self._own_device())
             self.waiting_queue.clear()
         else:
             reqs = [r for _, r in self.waiting_queue]
@@ -251,6 +252,12 @@ class DataParallelBatchScheduler:
                         o += meta[p]["batch"]
         mark("gather_s", t)
         return results if self.rank == 0 else None
+
+    def _own_device(self):
+        """Where this rank's requests must land: the stage's device if its model has one, else
+        whatever scatter_requests derives from the sender."""
+        d = self.stage_device()
+        return d if d.type != "cpu" or getattr(self.stage, "transformer", None) is not None else None
 
     def stage_device(self):
         """Device of the stage's model (used to shape empty contributions to a gather)."""

@@ -98,7 +98,8 @@ def scatter_requests(reqs, assign_fn, group=None, src: int = 0, device=None):
     every rank, managers/scheduler.py:291-314); a request's tensors go point to point to the one
     rank that runs it, all sends of a rank batched.  Returns (meta, mine): `meta[i]` describes
     request i on every rank (rank, batch, latent shape/dtype), `mine` maps this rank's
-    positions to Req objects on `device` (default: where rank `src` keeps them)."""
+    positions to Req objects on `device` (default: this rank's current GPU when rank `src` keeps
+    its requests on a GPU, else the host)."""
     import dataclasses
 
     from .denoise import Req
@@ -120,7 +121,11 @@ def scatter_requests(reqs, assign_fn, group=None, src: int = 0, device=None):
     dist.broadcast_object_list(box, src=_global_rank(group, src), group=group)
     meta = box[0]
     if device is None:
+        # the KIND of device rank `src` keeps its requests on, but this rank's own GPU: with one
+        # process per GPU "cuda:0" in rank 0's metadata is somebody else's device everywhere else
         device = torch.device(meta[0]["device"]) if meta else torch.device("cpu")
+        if device.type == "cuda":
+            device = torch.device("cuda", torch.cuda.current_device())
     on_host = dist.get_backend(group) == "gloo"
     ops, mine, landing = [], {}, []
     for i, m in enumerate(meta):
