@@ -52,8 +52,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 // f32 -> bf16 -> f32 (an eager-mode bf16 rounding point)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// (a two-element vector conversion, so that both halves come out of ONE v_cvt_pk_bf16_f32
+// wherever the call sits; two scalar casts are only merged when the compiler feels like it)
 __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 // Device pointer (for the current device) of the two counters that record bf16 -> half
