@@ -184,6 +184,9 @@ def main():
                     help="keep the double blocks' text-stream chain on the main stream (by default "
                          "it runs on a second HIP stream in the timed steps: same results; the "
                          "per-kernel accounting after the timed region is always un-overlapped)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the DiT forward of a step from a captured HIP graph (static input "
+                         "buffers; the scheduler update stays outside the graph)")
     ap.add_argument("--schnell", action="store_true",
                     help="Flux.1-schnell: no guidance embedder, bf16, batch 1, 4-step schedule "
                          "(a parity-test configuration; the result is NOT the metric)")
@@ -299,6 +302,36 @@ def main():
         noise = stage.predict_noise_with_cfg(req, latents.to(torch.bfloat16), t, guidance, freqs, i)
         latents = stage.scheduler.step(noise, ts_host[i], latents)[0]
         step_no[0] += 1
+
+    if args.graph:
+        # the forward is captured once on static buffers; a step copies its inputs in and replays
+        static_lat = latents.to(torch.bfloat16).clone()
+        static_t = timesteps[0].repeat(B).clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                stage.predict_noise_with_cfg(req, static_lat, static_t, guidance, freqs, 0)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph), torch.no_grad():
+            static_noise = stage.predict_noise_with_cfg(req, static_lat, static_t, guidance, freqs, 0)
+        eager_step = one_step
+
+        @torch.no_grad()
+        def one_step():
+            nonlocal latents
+            if model._engine.trace is not None:  # per-launch events cannot sit inside a replay
+                return eager_step()
+            i = step_no[0] % NUM_INFERENCE_STEPS
+            if i == 0:
+                stage.scheduler._step_index = None
+            static_lat.copy_(latents)
+            static_t.copy_(timesteps[i].expand(B))
+            graph.replay()
+            latents = stage.scheduler.step(static_noise, ts_host[i], latents)[0]
+            step_no[0] += 1
 
     def barrier():
         if world > 1:
@@ -458,6 +491,7 @@ def main():
                                 f"{args.mode}" + ("" if is_metric_config else " [NOT the metric config]")),
                    "global_batch": world * B, "seq_len": 4608, "parallelism": f"dp{world}",
                    "text_stream_overlap": bool(model._engine.overlap_text),
+                   "hip_graph": bool(args.graph),
                    "num_double_blocks": cfg.num_layers, "num_single_blocks": cfg.num_single_layers},
         "step_tflops_total": world * fl["total"] / step_s / 1e12,  # whole job
         "mfma_utilisation_vs_fp8_peak": fl["total"] / step_s / 1e12 / PEAK_FP8_TFLOPS,  # per GPU
