@@ -41,9 +41,13 @@ def shard_requests(num_requests: int, world_size: int, rank: int) -> range:
 
 def _wire(t: torch.Tensor, group=None) -> torch.Tensor:
     """The tensor a collective of `group` can carry: gloo moves host memory only, so device
-    tensors are staged through the host there (RCCL takes them as they are)."""
-    if t.is_cuda and dist.get_backend(group) == "gloo":
+    tensors are staged through the host there; RCCL moves device memory only, so host tensors
+    are staged through this rank's GPU."""
+    backend = dist.get_backend(group)
+    if t.is_cuda and backend == "gloo":
         return t.cpu()
+    if not t.is_cuda and backend == "nccl":
+        return t.to(torch.device("cuda", torch.cuda.current_device()))
     return t
 
 
@@ -58,12 +62,12 @@ def all_gather_tensors(x: torch.Tensor, group=None) -> List[torch.Tensor]:
 
 
 def _a2a(recv: torch.Tensor, send: torch.Tensor, group) -> None:
-    """all_to_all_single into `recv` (host-staged under gloo)."""
+    """all_to_all_single into `recv` (staged as `_wire` says when the backend cannot carry it)."""
     w = _wire(send, group)
     if w.device == send.device:
         dist.all_to_all_single(recv, send, group=group)
         return
-    r = torch.empty(recv.shape, dtype=recv.dtype, device="cpu")
+    r = torch.empty(recv.shape, dtype=recv.dtype, device=w.device)
     dist.all_to_all_single(r, w, group=group)
     recv.copy_(r)
 
@@ -127,6 +131,8 @@ def scatter_requests(reqs, assign_fn, group=None, src: int = 0, device=None):
         if device.type == "cuda":
             device = torch.device("cuda", torch.cuda.current_device())
     on_host = dist.get_backend(group) == "gloo"
+    # RCCL moves device memory only: host-resident requests are staged through this rank's GPU
+    wire = torch.device("cpu") if on_host else torch.device("cuda", torch.cuda.current_device())
     ops, mine, landing = [], {}, []
     for i, m in enumerate(meta):
         if me == src and m["rank"] == src:
@@ -134,12 +140,11 @@ def scatter_requests(reqs, assign_fn, group=None, src: int = 0, device=None):
         elif me == src:
             for k in m["tensors"]:
                 t = getattr(reqs[i], k).contiguous()
-                ops.append(dist.P2POp(dist.isend, t.cpu() if on_host else t,
-                                      _global_rank(group, m["rank"]), group))
+                ops.append(dist.P2POp(dist.isend, t.to(wire), _global_rank(group, m["rank"]), group))
         elif me == m["rank"]:
             got = {}
             for k, (shape, dtype) in m["tensors"].items():
-                got[k] = torch.empty(shape, dtype=dtype, device="cpu" if on_host else device)
+                got[k] = torch.empty(shape, dtype=dtype, device=wire)
                 ops.append(dist.P2POp(dist.irecv, got[k], _global_rank(group, src), group))
             landing.append((i, got))
     if ops:
