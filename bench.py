@@ -75,6 +75,7 @@ def launch_ranks(n: int, argv, timeout_s: float = 3300.0, script: str = None) ->
                                       env=env, stdout=None if r == 0 else sys.stderr))
     deadline = time.time() + timeout_s
     rc = 0
+    rank0_done = False
     live = dict(enumerate(procs))
     while live:
         for r, p in list(live.items()):
@@ -85,6 +86,11 @@ def launch_ranks(n: int, argv, timeout_s: float = 3300.0, script: str = None) ->
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 128 - code
                 print(f"[bench] rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+            if r == 0 and code == 0:
+                # the result line is out: the other ranks get a minute to leave their last
+                # collective, not the whole time limit
+                deadline = min(deadline, time.time() + 60.0)
+                rank0_done = True
         if (rc != 0 or time.time() > deadline) and live:
             for p in live.values():
                 p.terminate()
@@ -93,7 +99,7 @@ def launch_ranks(n: int, argv, timeout_s: float = 3300.0, script: str = None) ->
                     p.wait(20)
                 except subprocess.TimeoutExpired:
                     p.kill()
-            if rc == 0:
+            if rc == 0 and not rank0_done:
                 rc = 124
             break
         time.sleep(0.05)
@@ -458,11 +464,19 @@ def main():
     want_c4 = not args.no_c4 and not args.schnell
     if rank != 0:
         if want_c4:
+            import threading
+
+            # rank 0 gives the job up after --c4-timeout and prints its line without it; a rank
+            # still waiting in a collective then would keep the launcher waiting for ever
+            dog = threading.Timer(args.c4_timeout + 30.0, lambda: os._exit(0))
+            dog.daemon = True
+            dog.start()
             try:
                 run_c4()
             except Exception as e:  # rank 0 reports; a rank that cannot go on must not hang it
                 print(f"[rank {rank}] c4 workload failed: {type(e).__name__}: {e}", file=sys.stderr)
                 os._exit(1)
+            dog.cancel()
         if world > 1:
             dist.destroy_process_group()
         return
