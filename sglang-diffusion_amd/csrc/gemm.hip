@@ -313,15 +313,135 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
   }
 }
 
+// The same epilogue for accumulators of the 16x16 MFMA shapes (v_mfma_f32_16x16x32_bf16,
+// v_mfma_scale_f32_16x16x128_f8f6f4).  acc[ia][jb] is the 16-channel x 16-token block
+// (ia, jb) of the wave's tile: lane l holds token jb * 16 + (l & 15) and the four channels
+// ia * 16 + 4 * (l >> 4) .. + 3.  Element arithmetic, rounding points and the store phase are
+// those of gemm_epilogue; only the way a round's [32][64] image is written differs (8 bytes
+// per lane and block instead of 16 after an exchange).
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc)[TN * 2][TM * 2],
+                                                unsigned char* scratch, const float* sb_l,
+                                                const float* sa_l, const unsigned short* bias_l,
+                                                int m0, int n0, int wave, int lane) {
+  static_assert(TN % 2 == 0, "rounds cover two 32-channel blocks");
+  const int wm = wave % WAVES_M;
+  const int wn = wave / WAVES_M;
+  const int l16 = lane & 15;
+  const int q = lane >> 4;
+  const int lc = lane & 7, lr = lane >> 3;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    float sam[2] = {1.f, 1.f};
+    if constexpr (DT == 1) {
+      sam[0] = sa_l[wm * TM * 32 + j * 32 + l16];
+      sam[1] = sa_l[wm * TM * 32 + j * 32 + 16 + l16];
+    }
+    const int mw = m0 + wm * TM * 32 + j * 32;
+#pragma unroll
+    for (int ip = 0; ip < TN / 2; ++ip) {
+#pragma unroll
+      for (int i2 = 0; i2 < 2; ++i2) {
+        const int i = 2 * ip + i2;
+        // wave-uniform: the half-format column range is 32-aligned
+        const int nblk = n0 + wn * TN * 32 + i * 32;
+        const bool as_f16 = nblk >= p.f16_begin && nblk < p.f16_end;
+        float amax = 0.f;  // largest |value| of this 32-row x 32-channel block (half columns)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int nl = wn * TN * 32 + i * 32 + a * 16 + 4 * q;
+          f32x4 sbv = f32x4{1.f, 1.f, 1.f, 1.f};
+          if constexpr (DT == 1) sbv = *reinterpret_cast<const f32x4*>(sb_l + nl);
+          const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
+          const f32x4 bsv =
+              f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
+                    __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[i * 2 + a][j * 2 + b][e];
+              if constexpr (DT == 1) v = fmaf(v * sam[b], sbv[e], bsv[e]);
+              else v += bsv[e];
+              y[e] = v;
+            }
+            if (p.act == MI355_ACT_GELU_TANH) {
+              const f32x2 g0 = gelu_tanh_f2(f32x2{rbf(y[0]), rbf(y[1])});
+              const f32x2 g1 = gelu_tanh_f2(f32x2{rbf(y[2]), rbf(y[3])});
+              y[0] = g0[0];
+              y[1] = g0[1];
+              y[2] = g1[0];
+              y[3] = g1[1];
+            }
+            u32x2 pk;
+            if (as_f16) {
+              pk = u32x2{pack_bf2_as_f16(y[0], y[1]), pack_bf2_as_f16(y[2], y[3])};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(y[e]));
+            } else {
+              pk = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
+            }
+            const int row = b * 16 + l16;
+            const int chunk = i2 * 4 + a * 2 + (q >> 1);
+            *reinterpret_cast<u32x2*>(scratch + row * 128 + ((chunk ^ (row & 7)) << 4) +
+                                      (q & 1) * 8) = pk;
+          }
+        }
+        if (as_f16) note_f16_block(p.f16_counters, group_max<64>(amax), lane);
+      }
+      const int n8 = n0 + wn * TN * 32 + ip * 64 + lc * 8;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + lr;
+        const int m = mw + row;
+        u32x4 o = *reinterpret_cast<const u32x4*>(scratch + row * 128 + ((lc ^ (row & 7)) << 4));
+        if (m < p.M && n8 < p.N) {
+          const int64_t orow =
+              map_row32(m, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset) *
+              p.ldo;
+          if (p.gate) {
+            const int64_t grow = (int64_t)((unsigned)m / (unsigned)p.gate_rows) * p.ldg;
+            const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + grow + n8);
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + orow + n8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float y0 = __uint_as_float(o[e] << 16), y1 = __uint_as_float(o[e] & 0xffff0000u);
+              const float g0 = __uint_as_float(gv[e] << 16),
+                          g1 = __uint_as_float(gv[e] & 0xffff0000u);
+              const float r0 = __uint_as_float(rv[e] << 16),
+                          r1 = __uint_as_float(rv[e] & 0xffff0000u);
+              o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
+            }
+          }
+          __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(p.out + orow + n8));
+        }
+      }
+    }
+  }
+}
+
+// accumulator tile of one wave: 32x32 blocks of 16 registers, or 16x16 blocks of 4
+template <bool MF16, int TN, int TM>
+struct AccTile {
+  f32x16 v[TN][TM];
+};
+template <int TN, int TM>
+struct AccTile<true, TN, TM> {
+  f32x4 v[TN * 2][TM * 2];
+};
+
 // Persistent GEMM: the grid holds as many workgroups as fit on the chip at once and each
 // walks the output tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...  The operand stages
 // keep alternating across tile boundaries, so when a tile's K loop ends the stage it did NOT
 // use last is idle: the first K tile of the NEXT output tile is sent there by LDS-DMA before
 // the epilogue starts and lands underneath it, and the stage used last becomes the
 // epilogue's scratch (one 4-KiB slice per wave) and table area.
+// MF16: the 16x16 MFMA shapes instead of the 32x32 ones (plain per-token / bf16 form only).
 template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE,
-          bool OUT16 = false, bool KNORM = false>
+          bool OUT16 = false, bool KNORM = false, bool MF16 = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
+  static_assert(!MF16 || (!BLOCKSCALE && !OUT16 && !KNORM), "16x16 MFMAs: plain form only");
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -425,6 +545,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   const int x_row_off = (wm * TM * 32 + r) * 128;
   const int w_row_off = BM * 128 + (wn * TN * 32 + r) * 128;
   const int unit_scale = 0x7f7f7f7f;  // E8M0 127 = 2^0 in every byte
+  // 16x16 shapes: lane l reads row (l & 15) of a 16-row block and, of each K step, the 16-byte
+  // chunk (l >> 4) (bf16: K step = 32 elements = 4 chunks; fp8: the whole 128-byte K tile is one
+  // step and the lane takes chunks q and q + 4 -- any split of K over the lane groups works as
+  // long as both operands use the same one, and this one keeps the reads conflict-free under
+  // the row swizzle)
+  const int l16 = lane & 15;
+  const int q16 = lane >> 4;
+  const int swz16 = (l16 >> 1) & 7;
+  const int x_row_off16 = (wm * TM * 32 + l16) * 128;
+  const int w_row_off16 = BM * 128 + (wn * TN * 32 + l16) * 128;
+  const int coff16_0 = ((q16 ^ swz16) << 4);        // bf16 K step 0, fp8 low half
+  const int coff16_1 = (((q16 + 4) ^ swz16) << 4);  // bf16 K step 1, fp8 high half
 
   int vb = blockIdx.x;
   int m0, n0;
@@ -435,13 +567,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   stage(0);
 
   while (true) {
-    f32x16 acc[TN][TM];
+    AccTile<MF16, TN, TM> acct;
+    auto& acc = acct.v;
+    if constexpr (MF16) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+      for (int i = 0; i < TN * 2; ++i)
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+        for (int j = 0; j < TM * 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
 
     // block-scaled variant: scale row pointers
     const float* sa_row[TM];
@@ -483,7 +623,56 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
       if (kt + 1 < p.ktiles) stage(cur ^ 1);
       const unsigned char* sbase = smem + cur * STAGE_BYTES;
 
-      if constexpr (BLOCKSCALE) {
+      if constexpr (MF16) {
+        const unsigned char* xb = sbase + x_row_off16;
+        const unsigned char* wb = sbase + w_row_off16;
+        if constexpr (DT == 0) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int co = s ? coff16_1 : coff16_0;
+            bf16x8 af[TN * 2], bfr[TM * 2];
+#pragma unroll
+            for (int j = 0; j < TM * 2; ++j)
+              bfr[j] = *reinterpret_cast<const bf16x8*>(xb + j * 16 * 128 + co);
+#pragma unroll
+            for (int i = 0; i < TN * 2; ++i)
+              af[i] = *reinterpret_cast<const bf16x8*>(wb + i * 16 * 128 + co);
+#pragma unroll
+            for (int i = 0; i < TN * 2; ++i)
+#pragma unroll
+              for (int j = 0; j < TM * 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          }
+        } else {
+          i32x8 bfr[TM * 2];
+#pragma unroll
+          for (int j = 0; j < TM * 2; ++j) {
+            const unsigned char* pb = xb + j * 16 * 128;
+            const i32x4 lo = *reinterpret_cast<const i32x4*>(pb + coff16_0);
+            const i32x4 hi = *reinterpret_cast<const i32x4*>(pb + coff16_1);
+            bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+          // the weight fragments in groups of four (a 256-register budget at 2 waves per SIMD)
+#pragma unroll
+          for (int ig = 0; ig < TN * 2; ig += 4) {
+            if constexpr (TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);
+            i32x8 af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const unsigned char* pa = wb + (ig + i) * 16 * 128;
+              const i32x4 lo = *reinterpret_cast<const i32x4*>(pa + coff16_0);
+              const i32x4 hi = *reinterpret_cast<const i32x4*>(pa + coff16_1);
+              af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < TM * 2; ++j)
+                acc[ig + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                    af[i], bfr[j], acc[ig + i][j], 0, 0, 0, unit_scale, 0, unit_scale);
+          }
+        }
+      } else if constexpr (BLOCKSCALE) {
         // One K tile is one 128-wide scale block.  The K tile is walked in TN*TM units of one
         // 32x32 output block each: a unit's MFMAs (a chain over the K steps, started from
         // zero) go into one of two partial tiles, and while they run the PREVIOUS unit's
@@ -622,8 +811,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
       load_tables(m0, n0);
     }
     __syncthreads();  // tables visible
-    gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE, OUT16, KNORM>(p, acc, area + wave * SCRATCH_WAVE, sb_l,
-                                                            sa_l, bias_l, em0, en0, wave, lane);
+    if constexpr (MF16)
+      gemm_epilogue16<DT, WAVES_M, WAVES_N, TM, TN>(p, acc, area + wave * SCRATCH_WAVE, sb_l, sa_l,
+                                                    bias_l, em0, en0, wave, lane);
+    else
+      gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE, OUT16, KNORM>(
+          p, acc, area + wave * SCRATCH_WAVE, sb_l, sa_l, bias_l, em0, en0, wave, lane);
     if (!more) break;
     vb = nvb;
   }
@@ -970,7 +1163,7 @@ int resident_workgroups(int lds_bytes) {
 }
 
 template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS, bool OUT16 = false,
-          bool KNORM = false>
+          bool KNORM = false, bool MF16 = false>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int LDS = 2 * (BM + BN) * 128;
@@ -981,7 +1174,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
-  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16, KNORM>;
+  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16, KNORM, MF16>;
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1180,8 +1373,21 @@ int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hip
                : launch_gemm<0, 4, 2, 2, 4, false, false, true>(p, st);
   if (block_scale)
     return big ? launch_gemm<1, 4, 2, 2, 4, true>(p, st) : launch_gemm<1, 2, 2, 2, 2, true>(p, st);
-  if (fp8)
+  // The plain forms run on the 16x16 MFMA shapes: same bits as the 32x32 shapes (measured over
+  // every element of K = 15360 outputs) and 2-6 % (fp8) / 5-8 % (bf16) less time on the Flux
+  // shapes -- the chip is power-capped under these kernels and holds a higher clock with them.
+  // MI355_GEMM_MFMA16 (bit 0 bf16, bit 1 fp8; read per call) picks the shape for A/B timing.
+  const char* mf = getenv("MI355_GEMM_MFMA16");
+  const int mf16 = mf ? atoi(mf) : 3;
+  if (fp8) {
+    if (mf16 & 2)
+      return big ? launch_gemm<1, 4, 2, 2, 4, false, false, false, true>(p, st)
+                 : launch_gemm<1, 2, 2, 2, 2, false, false, false, true>(p, st);
     return big ? launch_gemm<1, 4, 2, 2, 4, false>(p, st) : launch_gemm<1, 2, 2, 2, 2, false>(p, st);
+  }
+  if (mf16 & 1)
+    return big ? launch_gemm<0, 4, 2, 2, 4, false, false, false, true>(p, st)
+               : launch_gemm<0, 2, 2, 2, 2, false, false, false, true>(p, st);
   return big ? launch_gemm<0, 4, 2, 2, 4, false>(p, st) : launch_gemm<0, 2, 2, 2, 2, false>(p, st);
 }
 
