@@ -448,6 +448,374 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
   }
 }
 
+// ---- the same computation on the 16x16x32 MFMA shapes ------------------------------------------
+// The chip is power-capped under this kernel and holds a higher clock on the 16x16 shapes
+// (tools/probes/mfma_shape.hip).  Per wave still 32 query rows and 64-key tiles; what changes is
+// who holds what.  With li = lane & 15 and g = lane >> 4:
+//   S^T block (kb, jb) = K rows 16 kb .. x Q rows 16 jb ..: lane holds query 16 jb + li and
+//       keys 16 kb + 4 g + e (e = 0..3).  A row's 64 scores sit in FOUR lanes, so a lane
+//       compares only its own 16 scores with the running reference point; the cross-lane row
+//       maximum (two exchanges) is taken only when some lane of the wave has outgrown it.
+//   P^T operand of the P.V MFMA over keys 32 kp ..: k index 8 g + j  <->  key
+//       32 kp + 16 (j >> 2) + 4 g + (j & 3), i.e. the accumulators of blocks 2 kp and 2 kp + 1 as
+//       they stand; the V^T operand is read with the same assignment (two transposed reads of
+//       4 keys x 16 columns per 16-lane group).
+//   O^T block (d, jb): lane holds query 16 jb + li, columns 16 d + 4 g + e.
+// The V image uses its own chunk swizzle, (key & 7) << 1: a transposed read touches two chunks
+// in each of eight rows per half-wave, and this spreads them over all sixteen 16-byte slots.
+__device__ __forceinline__ int v_swz16(int key) { return (key & 7) << 1; }
+
+// Q fragments (B operand) of one 16-row query block: lane -> row qrow, d = 32 s + 8 g + 0..7.
+// Norm / rotation as load_q_fragments: chunk 4 s + g of the row sits in step s of this lane, so
+// the butterfly over chunk-index bits 3, 2 runs inside the lane and bits 1, 0 are exchanges
+// with the lanes 32 and 16 away.
+template <int D, int KS>
+__device__ __forceinline__ void load_q_fragments16(const AttnParams& p, int b, int head, int qrow,
+                                                   int g, bf16x8 (&qf)[KS]) {
+  if (qrow >= p.Sq) qrow = p.Sq - 1;
+  const unsigned short* qp = p.q + b * p.q_sb + (int64_t)qrow * p.q_ss + head * p.q_sh;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 32 * s + 8 * g);
+  if (p.qw1 || p.qcos) {
+    float f[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[s][j] = (float)qf[s][j];
+    const float* wsel = qrow < p.q_split ? p.qw0 : p.qw1;
+    if (wsel) {
+      float c2[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        c2[s] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c2[s] += f[s][j] * f[s][j];
+      }
+#pragma unroll
+      for (int w = KS / 2; w >= 1; w >>= 1)
+#pragma unroll
+        for (int s = 0; s < w; ++s) c2[s] = c2[s] + c2[s + w];
+      float sq = c2[0] + __shfl_xor(c2[0], 32, 64);
+      sq = sq + __shfl_xor(sq, 16, 64);
+      const float rs = rsqrtf(sq / (float)D + p.q_eps);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const f32x4 wa = reinterpret_cast<const f32x4*>(wsel)[2 * (4 * s + g)];
+        const f32x4 wb = reinterpret_cast<const f32x4*>(wsel)[2 * (4 * s + g) + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f[s][j] = rbf((f[s][j] * rs) * wa[j]);
+          f[s][4 + j] = rbf((f[s][4 + j] * rs) * wb[j]);
+        }
+      }
+    }
+    if (p.qcos) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const f32x4 cs = reinterpret_cast<const f32x4*>(p.qcos + (int64_t)qrow * (D / 2))[4 * s + g];
+        const f32x4 sn = reinterpret_cast<const f32x4*>(p.qsin + (int64_t)qrow * (D / 2))[4 * s + g];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x1 = f[s][2 * j], x2 = f[s][2 * j + 1];
+          f[s][2 * j] = fmaf(-x2, sn[j], __fmul_rn(x1, cs[j]));
+          f[s][2 * j + 1] = fmaf(x1, sn[j], __fmul_rn(x2, cs[j]));
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (__bf16)f[s][j];
+  }
+}
+
+template <int D, bool F16, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd16_kernel(AttnParams p) {
+  constexpr int KV = 64;
+  constexpr int ROWB = D * 2;
+  constexpr int CPR = ROWB / 16;
+  constexpr int TILE_BYTES = KV * ROWB;
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int PIECES = 2 * TILE_BYTES / 1024 / NW;
+  constexpr int KS = D / 32;    // QK^T k-steps
+  constexpr int DV16 = D / 16;  // 16-wide dv blocks
+  static_assert(D == 128, "the V swizzle is laid out for 256-byte rows");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15;
+  const int g = lane >> 4;
+
+  // XCD-contiguous work ranges, as attn_fwd_kernel
+  int qb, head, b;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned per = total >> 3, rem = total & 7, xcd = lin & 7;
+    const unsigned wid =
+        (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (lin >> 3);
+    qb = (int)(wid % gx);
+    const unsigned bh = wid / gx;
+    head = (int)(bh % gy);
+    b = (int)(bh / gy);
+  }
+  const int hk = head / (p.H / p.Hk);
+  const int q0 = qb * (NW * 32) + wave * 32;
+
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) load_q_fragments16<D, KS>(p, b, head, q0 + jb * 16 + li, g, qf[jb]);
+
+  // ---- LDS-DMA sources: [K tile | V tile], 1-KiB pieces --------------------------------------
+  const unsigned char* kbase =
+      reinterpret_cast<const unsigned char*>(p.k + b * p.k_sb + hk * p.k_sh);
+  const unsigned char* vbase =
+      reinterpret_cast<const unsigned char*>(p.v + b * p.v_sb + hk * p.v_sh);
+  static_assert(PIECES % 2 == 0, "first half of a wave's pieces is K, second half V");
+  int prow[PIECES];
+  int pchunk[PIECES];
+  unsigned int voff[PIECES];
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    const int piece = wave + NW * i;
+    const int lin = piece * 64 + lane;
+    const int slot = lin % (TILE_BYTES / 16);
+    const bool isv = i >= PIECES / 2;
+    const int row = slot / CPR;
+    const int pc = slot % CPR;
+    prow[i] = row;
+    pchunk[i] = isv ? (pc ^ (v_swz16(row) & (CPR - 1))) : (pc ^ (k_swz(row) & (CPR - 1)));
+    voff[i] = (unsigned int)(row * (isv ? p.v_ss : p.k_ss) * 2 + pchunk[i] * 16);
+  }
+  const int64_t k_tile_step = (int64_t)KV * p.k_ss * 2, v_tile_step = (int64_t)KV * p.v_ss * 2;
+
+  auto stage = [&](int buf, int k0) {
+    if (k0 + KV <= p.Sk) {
+      const unsigned char* kt0 = kbase + (int64_t)(k0 / KV) * k_tile_step;  // wave-uniform
+      const unsigned char* vt0 = vbase + (int64_t)(k0 / KV) * v_tile_step;
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const int piece = wave + NW * i;
+        const unsigned char* src = (i >= PIECES / 2 ? vt0 : kt0) + voff[i];
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
+                                         (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16,
+                                         0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const int piece = wave + NW * i;
+        int key = k0 + prow[i];
+        if (key >= p.Sk) key = p.Sk - 1;
+        const unsigned char* src = i >= PIECES / 2
+                                       ? vbase + ((int64_t)key * p.v_ss * 2 + pchunk[i] * 16)
+                                       : kbase + ((int64_t)key * p.k_ss * 2 + pchunk[i] * 16);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src,
+                                         (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16,
+                                         0, 0);
+      }
+    }
+  };
+
+  // ---- per-lane LDS read offsets ----------------------------------------------------------
+  // K row read (A operand): row 16 kb + li, chunk 4 s + g
+  int koff[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) koff[s] = li * ROWB + (((4 * s + g) ^ (k_swz(li) & (CPR - 1))) << 4);
+  // V transposed read (A operand of P.V): the 16-lane group g reads keys .. + 4 g + qq
+  // (qq = li >> 2), columns 16 d + 4 pp .. + 3 (pp = li & 3), and gets back column 16 d + li
+  // of those four keys.  The swizzle only sees key bits 0..2, so the (kp, half) part of the key
+  // is an immediate offset.
+  const int qq = li >> 2, pp = li & 3;
+  int vlane[DV16];
+#pragma unroll
+  for (int d = 0; d < DV16; ++d) {
+    const int key = 4 * g + qq;
+    vlane[d] = key * ROWB + ((((2 * d + (pp >> 1)) ^ (v_swz16(key) & (CPR - 1)))) << 4) + ((pp & 1) << 3);
+  }
+
+  f32x4 oacc[DV16][2];
+#pragma unroll
+  for (int d = 0; d < DV16; ++d)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) oacc[d][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY};  // reference point of the exponentials (raw scores)
+  float l_run[2] = {0.f, 0.f};              // this lane's partial row sums (its 16 of every 64 keys)
+  const float c = p.scale_log2;
+
+  const int ntiles = (p.Sk + KV - 1) / KV;
+  stage(0, 0);
+  auto tile_body = [&](auto bufc, int t) {
+    constexpr int cur = decltype(bufc)::value;
+    const int k0 = t * KV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles && !(p.ablate == 1 && t > 0)) stage(cur ^ 1, k0 + KV);
+    const unsigned char* kt = smem + cur * STAGE_BYTES;
+    const unsigned char* vt = kt + TILE_BYTES;
+
+    // ---- S^T = K Q^T : four 16-key blocks x two 16-query blocks -------------------------
+    f32x4 sacc[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) sacc[kb][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_setprio(2);
+    {
+      bf16x8 kf[2][4];  // [parity of step][kb]
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        kf[0][kb] = *reinterpret_cast<const bf16x8*>(kt + kb * 16 * ROWB + koff[0]);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+            kf[(s + 1) & 1][kb] =
+                *reinterpret_cast<const bf16x8*>(kt + kb * 16 * ROWB + koff[s + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads of step s+1 ahead of step s's MFMAs
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb)
+            sacc[kb][jb] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s & 1][kb], qf[jb][s], sacc[kb][jb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // mask keys past the end (last tile only; wave-uniform branch)
+    if (k0 + KV > p.Sk) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = k0 + kb * 16 + 4 * g + e;
+          if (key >= p.Sk) {
+            sacc[kb][0][e] = -INFINITY;
+            sacc[kb][1][e] = -INFINITY;
+          }
+        }
+    }
+    // ---- online softmax ---------------------------------------------------------------
+    // Lazy reference point (see attn_fwd_kernel): it moves only when some lane's own scores
+    // have outgrown it by 2^LAZY_LOG2; only then is the row maximum taken across the four lanes
+    // of a row, so that they move to the same point.
+    constexpr float LAZY_LOG2 = 8.0f;
+    float mxl[2];
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      mxl[jb] = sacc[0][jb][0];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mxl[jb] = fmaxf(mxl[jb], sacc[kb][jb][e]);
+    }
+    const bool outgrown =
+        (mxl[0] - m_run[0]) * c > LAZY_LOG2 || (mxl[1] - m_run[1]) * c > LAZY_LOG2;
+    if (__builtin_amdgcn_ballot_w64(outgrown) != 0) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        float mx = mxl[jb];
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[jb], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[jb] - m_new) * c);
+        m_run[jb] = m_new;
+        l_run[jb] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DV16; ++d) oacc[d][jb] *= alpha;
+      }
+    }
+    typedef typename std::conditional<F16, f16x8, bf16x8>::type pfrag_t;
+    pfrag_t pf[2][2];  // [kp][jb]
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const float mc = m_run[jb] * c;
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[kb][jb][e], c, -mc));
+          rs += pe;
+          if constexpr (F16) pf[kb >> 1][jb][(kb & 1) * 4 + e] = (_Float16)pe;
+          else pf[kb >> 1][jb][(kb & 1) * 4 + e] = (__bf16)pe;
+        }
+      l_run[jb] += rs;
+    }
+    __builtin_amdgcn_s_setprio(2);
+
+    // ---- O^T += V^T P^T ---------------------------------------------------------------
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+      for (int d = 0; d < DV16; ++d) {
+        const int off0 = vlane[d] + (kp * 32) * ROWB, off1 = vlane[d] + (kp * 32 + 16) * ROWB;
+        if constexpr (F16) {
+          const f16x4 t0 = __builtin_bit_cast(
+              f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                         (__attribute__((address_space(3))) hw_f16x4*)(vt + off0)));
+          const f16x4 t1 = __builtin_bit_cast(
+              f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                         (__attribute__((address_space(3))) hw_f16x4*)(vt + off1)));
+          const f16x8 vf = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb)
+            oacc[d][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[kp][jb], oacc[d][jb], 0, 0, 0);
+        } else {
+          const bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(vt + off0));
+          const bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(vt + off1));
+          const bf16x8 vf = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb)
+            oacc[d][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kp][jb], oacc[d][jb], 0, 0, 0);
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile_body(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile_body(std::integral_constant<int, 1>{}, t + 1);
+  }
+
+  // ---- finish: combine the four partial row sums, normalise, store --------------------------
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    float l_tot = l_run[jb] + __shfl_xor(l_run[jb], 16, 64);
+    l_tot = l_tot + __shfl_xor(l_tot, 32, 64);
+    const float inv_l = 1.0f / l_tot;
+    const int qrow = q0 + jb * 16 + li;
+    const bool q_ok = qrow < p.Sq;
+    if (p.lse && q_ok && g == 0) {
+      p.lse[((int64_t)b * p.H + head) * p.Sq + qrow] =
+          (m_run[jb] * c + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+    }
+    unsigned short* op = p.o + b * p.o_sb + (int64_t)(q_ok ? qrow : 0) * p.o_ss + head * p.o_sh;
+    // lanes g and g ^ 1 exchange so that each stores 8 consecutive columns: the even one those
+    // of dv block 2 m, the odd one those of block 2 m + 1
+#pragma unroll
+    for (int m = 0; m < DV16 / 2; ++m) {
+      unsigned int a0 = pack_bf2(oacc[2 * m][jb][0] * inv_l, oacc[2 * m][jb][1] * inv_l);
+      unsigned int a1 = pack_bf2(oacc[2 * m][jb][2] * inv_l, oacc[2 * m][jb][3] * inv_l);
+      unsigned int b0 = pack_bf2(oacc[2 * m + 1][jb][0] * inv_l, oacc[2 * m + 1][jb][1] * inv_l);
+      unsigned int b1 = pack_bf2(oacc[2 * m + 1][jb][2] * inv_l, oacc[2 * m + 1][jb][3] * inv_l);
+      auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+      auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+      if (q_ok) {
+        const int dv8 = (2 * m + (g & 1)) * 16 + 8 * (g >> 1);
+        *reinterpret_cast<u32x4*>(op + dv8) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+  }
+}
+
 // ---- two-phase ("ping-pong") variant: head size 128, 8 waves ----------------------------------
 // attn_fwd_kernel runs every wave through  S = K Q^T (MFMA) -> softmax (vector) -> O += V^T P
 // (MFMA)  behind one barrier per tile, so the two waves that share a SIMD are always in the SAME
@@ -854,7 +1222,8 @@ int launch_attn_pingpong(const AttnParams& p, hipStream_t st) {
   return MI355_OK;
 }
 
-template <int D, bool TRREAD, bool F16, int NW = 4>
+// M16: attn_fwd16_kernel (the 16x16x32 MFMA shapes; head size 128) instead of attn_fwd_kernel
+template <int D, bool TRREAD, bool F16, int NW = 4, bool M16 = false>
 int launch_attn(const AttnParams& p, hipStream_t st) {
   if constexpr (NW == 4) {
     // Eight waves (256 query rows) share each K/V tile once the launch still has a workgroup
@@ -869,7 +1238,7 @@ int launch_attn(const AttnParams& p, hipStream_t st) {
         n = 256;
       cus.store(n, std::memory_order_relaxed);
     }
-    if (((p.Sq + 255) / 256) * (int64_t)p.H * p.B >= n) return launch_attn<D, TRREAD, F16, 8>(p, st);
+    if (((p.Sq + 255) / 256) * (int64_t)p.H * p.B >= n) return launch_attn<D, TRREAD, F16, 8, M16>(p, st);
   }
   constexpr int LDS = 2 * 2 * 64 * D * 2;
   // the LDS limit is a per-device function attribute: remember which devices have it
@@ -879,7 +1248,9 @@ int launch_attn(const AttnParams& p, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
-  auto kfn = attn_fwd_kernel<D, TRREAD, F16, NW>;
+  void (*kfn)(AttnParams);
+  if constexpr (M16) kfn = attn_fwd16_kernel<D, F16, NW>;
+  else kfn = attn_fwd_kernel<D, TRREAD, F16, NW>;
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -959,6 +1330,13 @@ static int attn_entry(const void* q, const void* k, const void* v, void* out, fl
   hipStream_t st = (hipStream_t)stream;
   if (D == 128 && getenv("MI355_ATTN_PINGPONG") != nullptr)
     return v_f16 ? launch_attn_pingpong<true>(p, st) : launch_attn_pingpong<false>(p, st);
+  // A/B switch while the 16x16 MFMA form is being measured (read per call)
+  {
+    const char* m16 = getenv("MI355_ATTN_MFMA16");
+    if (D == 128 && m16 && atoi(m16) != 0)
+      return v_f16 ? launch_attn<128, true, true, 4, true>(p, st)
+                   : launch_attn<128, true, false, 4, true>(p, st);
+  }
   if (v_f16) return D == 128 ? launch_attn<128, true, true>(p, st) : launch_attn<64, true, true>(p, st);
   static const bool no_tr = getenv("MI355_ATTN_NO_TR") != nullptr;  // debugging aid
   if (no_tr)

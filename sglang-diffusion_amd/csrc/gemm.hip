@@ -439,9 +439,10 @@ struct AccTile<true, TN, TM> {
 // epilogue's scratch (one 4-KiB slice per wave) and table area.
 // MF16: the 16x16 MFMA shapes instead of the 32x32 ones (plain per-token / bf16 form only).
 template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE,
-          bool OUT16 = false, bool KNORM = false, bool MF16 = false>
+          bool OUT16 = false, bool KNORM = false, bool MF16 = false, bool PIPE = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
   static_assert(!MF16 || (!BLOCKSCALE && !OUT16 && !KNORM), "16x16 MFMAs: plain form only");
+  static_assert(!PIPE || (MF16 && DT == 0), "pipelined K loop: bf16 on the 16x16 shape");
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -616,6 +617,77 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
       }
     }
 
+    if constexpr (PIPE) {
+      // Software-pipelined K loop (bf16; the fp8 form of it does not fit 256 registers beside the
+      // accumulators: 67 spills, not kept).  A K tile is walked in units of two weight
+      // fragments = 8 MFMAs; the fragments of unit u + 1 are requested from LDS
+      // before the MFMAs of unit u are issued, and the wait + barrier that opens the NEXT K tile
+      // sits inside the LAST unit of this one: by then every wave has all of this tile's
+      // fragments in registers, so the stage can be refilled while the last MFMAs run.
+      {
+        const int cur0 = g & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (p.ktiles > 1) stage(cur0 ^ 1);
+      }
+      {
+        constexpr int NIG = TN;      // units per K step (two 16-row weight fragments each)
+        constexpr int NU = 2 * NIG;  // units per K tile (two K steps of 32)
+        bf16x8 afb[2][2], bfb[2][TM * 2];
+        {
+          const unsigned char* xb = smem + (g & 1) * STAGE_BYTES + x_row_off16;
+          const unsigned char* wb = smem + (g & 1) * STAGE_BYTES + w_row_off16;
+#pragma unroll
+          for (int j = 0; j < TM * 2; ++j)
+            bfb[0][j] = *reinterpret_cast<const bf16x8*>(xb + j * 16 * 128 + coff16_0);
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            afb[0][a] = *reinterpret_cast<const bf16x8*>(wb + a * 16 * 128 + coff16_0);
+        }
+        for (int kt = 0; kt < p.ktiles; ++kt, ++g) {
+          const int cur = g & 1;
+          const unsigned char* xb = smem + cur * STAGE_BYTES + x_row_off16;
+          const unsigned char* wb = smem + cur * STAGE_BYTES + w_row_off16;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            const int ks = u / NIG, ig = u % NIG;
+            if (u + 1 < NU) {
+              const int ks1 = (u + 1) / NIG, ig1 = (u + 1) % NIG;
+              const int co1 = ks1 ? coff16_1 : coff16_0;
+              if (ig1 == 0) {
+#pragma unroll
+                for (int j = 0; j < TM * 2; ++j)
+                  bfb[ks1][j] = *reinterpret_cast<const bf16x8*>(xb + j * 16 * 128 + co1);
+              }
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+                afb[(u + 1) & 1][a] =
+                    *reinterpret_cast<const bf16x8*>(wb + (2 * ig1 + a) * 16 * 128 + co1);
+            } else if (kt + 1 < p.ktiles) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              __syncthreads();
+              if (kt + 2 < p.ktiles) stage(cur);
+              const unsigned char* xn = smem + (cur ^ 1) * STAGE_BYTES + x_row_off16;
+              const unsigned char* wn = smem + (cur ^ 1) * STAGE_BYTES + w_row_off16;
+#pragma unroll
+              for (int j = 0; j < TM * 2; ++j)
+                bfb[0][j] = *reinterpret_cast<const bf16x8*>(xn + j * 16 * 128 + coff16_0);
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+                afb[0][a] = *reinterpret_cast<const bf16x8*>(wn + a * 16 * 128 + coff16_0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int j = 0; j < TM * 2; ++j)
+                acc[2 * ig + a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    afb[u & 1][a], bfb[ks][j], acc[2 * ig + a][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    } else
     for (int kt = 0; kt < p.ktiles; ++kt, ++g) {
       const int cur = g & 1;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1163,7 +1235,7 @@ int resident_workgroups(int lds_bytes) {
 }
 
 template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS, bool OUT16 = false,
-          bool KNORM = false, bool MF16 = false>
+          bool KNORM = false, bool MF16 = false, bool PIPE = false>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int LDS = 2 * (BM + BN) * 128;
@@ -1174,7 +1246,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
-  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16, KNORM, MF16>;
+  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16, KNORM, MF16, PIPE>;
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1385,6 +1457,11 @@ int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hip
                  : launch_gemm<1, 2, 2, 2, 2, false, false, false, true>(p, st);
     return big ? launch_gemm<1, 4, 2, 2, 4, false>(p, st) : launch_gemm<1, 2, 2, 2, 2, false>(p, st);
   }
+  // bf16: the software-pipelined K loop (same bits, 3-4 % less time; MI355_GEMM_PIPE=0 for A/B)
+  const char* pipe = getenv("MI355_GEMM_PIPE");
+  if ((mf16 & 1) && !(pipe && atoi(pipe) == 0))
+    return big ? launch_gemm<0, 4, 2, 2, 4, false, false, false, true, true>(p, st)
+               : launch_gemm<0, 2, 2, 2, 2, false, false, false, true, true>(p, st);
   if (mf16 & 1)
     return big ? launch_gemm<0, 4, 2, 2, 4, false, false, false, true>(p, st)
                : launch_gemm<0, 2, 2, 2, 2, false, false, false, true>(p, st);

@@ -953,3 +953,129 @@ def test_linear_ex_fused_key_norm_equals_the_separate_pass(device, fp8, M, rows_
         _C.qk_norm_rope(None, ref.view(1, M, 3, H, D)[:, :, 1], nw, nw, nw, nw, 0, 1e-6, cos, sin, True)
     torch.cuda.synchronize()
     assert torch.equal(fused.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("M,N,K", [(300, 264, 256), (1000, 520, 192), (2048, 1536, 3072), (129, 8, 128)])
+def test_linear_mfma_shapes_and_pipelined_loop_give_the_same_bits(device, fp8, M, N, K, monkeypatch):
+    """The plain linears run on the 16x16 MFMA shapes (bf16: with the software-pipelined K
+    loop); MI355_GEMM_MFMA16=0 selects the 32x32 shapes and MI355_GEMM_PIPE=0 the plain loop.
+    All forms must give the same bits: ragged tiles, GELU epilogue, gate / residual through row
+    maps, half-format output columns."""
+    if fp8 and K % 128:
+        K = 256
+    x = torch.randn(M, K, generator=g(301)).bfloat16()
+    w = (torch.randn(N, K, generator=g(302)) * K ** -0.5).bfloat16()
+    b = (torch.randn(N, generator=g(303)) * 0.1).bfloat16()
+    gate = torch.randn(1, N, generator=g(304)).bfloat16().to(device)
+    res = torch.randn(M, N, generator=g(305)).bfloat16().to(device)
+    kw = {}
+    if fp8:
+        xq, xs = ops.per_token_quant_fp8(x)
+        wq, ws = ops.quantize_weight_per_channel(w)
+        a_d, w_d = xq.to(device), wq.to(device)
+        kw = dict(sa=xs.view(-1).to(device), sb=ws.to(device), fp8=True)
+    else:
+        a_d, w_d = x.to(device), w.to(device)
+    variants = [dict(bias=b.to(device)), dict(bias=b.to(device), act=1),
+                dict(bias=b.to(device), gate=gate, residual=True, ldg=N, gate_rows=M)]
+    if N % 32 == 0 and N >= 64:
+        variants.append(dict(bias=b.to(device), f16_cols=(N - 32, N)))
+
+    def run(v):
+        v = dict(v)
+        out = res.clone() if v.pop("residual", False) else torch.empty(M, N, dtype=torch.bfloat16, device=device)
+        if "gate" in v:
+            v["residual"] = out
+        _C.linear_ex(a_d, w_d, out, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, **v, **kw)
+        torch.cuda.synchronize()
+        return out
+
+    for v in variants:
+        base = run(v)
+        for env in ({"MI355_GEMM_MFMA16": "0"}, {"MI355_GEMM_PIPE": "0"}):
+            for k_, val in env.items():
+                monkeypatch.setenv(k_, val)
+            other = run(v)
+            for k_ in env:
+                monkeypatch.delenv(k_)
+            assert torch.equal(base.view(torch.int16), other.view(torch.int16)), (env, sorted(v))
+
+
+@pytest.mark.parametrize("half_v", [True, False])
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk", [(1, 64, 64, 2, 2), (2, 300, 333, 4, 2), (2, 257, 129, 2, 1),
+                                           (1, 31, 1, 2, 2), (1, 700, 1100, 3, 3)])
+def test_attention_on_the_small_mfma_shape_vs_oracle(device, B, Sq, Sk, H, Hk, half_v, monkeypatch):
+    """attn_fwd16_kernel (MI355_ATTN_MFMA16=1: the 16x16x32 MFMA shapes, four lanes per query row)
+    against the oracle at the shipped kernel's tolerances: ragged query / key tiles, grouped
+    heads, both P.V precisions, output and LSE."""
+    D = 128
+    q = torch.randn(B, Sq, H, D, generator=g(311)).bfloat16()
+    k = torch.randn(B, Sk, Hk, D, generator=g(312)).bfloat16()
+    v = torch.randn(B, Sk, Hk, D, generator=g(313)).bfloat16()
+    kk, vv = k.repeat_interleave(H // Hk, 2), v.repeat_interleave(H // Hk, 2)
+    ref, lse_ref = ops.attention(q, kk, vv, return_lse=True)
+    monkeypatch.setenv("MI355_ATTN_MFMA16", "1")
+    out = torch.full((B, Sq, H, D), float("nan"), dtype=torch.bfloat16, device=device)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=device)
+    vd = v.to(device)
+    _C.flash_attn_fwd(q.to(device), k.to(device), _C.value_to_f16(vd) if half_v else vd, out, lse,
+                      D ** -0.5, v_is_f16=half_v)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) <= (1e-3 if half_v else 4e-3)
+    assert (lse.cpu() - lse_ref).abs().max() <= 2e-3
+
+
+def test_attention_on_the_small_mfma_shape_moves_its_reference_point(device, monkeypatch):
+    """The 16x16 kernel takes the cross-lane row maximum only when some lane's own scores have
+    outgrown the reference point: a spike late in the key sequence (one lane of one row sees it)
+    and steadily climbing scores (the point moves several times, probabilities above 1 in
+    between) must both match the oracle, and the fused query norm + rotation must match the
+    shipped kernel's."""
+    monkeypatch.setenv("MI355_ATTN_MFMA16", "1")
+    B, S, H, D = 1, 256, 1, 128
+    q = torch.randn(B, S, H, D, generator=g(44)).bfloat16()
+    k = torch.randn(B, S, H, D, generator=g(45)).bfloat16()
+    v = torch.randn(B, S, H, D, generator=g(46)).bfloat16()
+    k[0, 200, 0] = q[0, 17, 0] * 4
+    ref = ops.attention(q, k, v)
+    out = torch.empty_like(q, device=device)
+    _C.flash_attn_fwd(q.to(device), k.to(device), v.to(device), out, None, D ** -0.5)
+    assert rel_l2(out, ref) <= 4e-3
+    assert rel_l2(out[0, 17], ref[0, 17]) <= 1e-2
+
+    B, S, H = 1, 1024, 2
+    q = torch.randn(B, S, H, D, generator=g(81)).bfloat16()
+    k = torch.randn(B, S, H, D, generator=g(82)).bfloat16() * 0.3
+    v = torch.randn(B, S, H, D, generator=g(83)).bfloat16()
+    u = q.float().mean(dim=1, keepdim=True)
+    u = u / u.norm(dim=-1, keepdim=True)
+    k = (k.float() + torch.linspace(0, 1, S).view(1, S, 1, 1) * u * 40.0).bfloat16()
+    ref, lse_ref = ops.attention(q, k, v, return_lse=True)
+    for fn, tol in ((_C.flash_attn_fwd, 4e-3), (_C.attention, 1.5e-3)):
+        out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=device)
+        lse = torch.empty(B, H, S, dtype=torch.float32, device=device)
+        fn(q.to(device), k.to(device), v.to(device), out, lse, D ** -0.5)
+        assert torch.isfinite(out.float()).all()
+        assert rel_l2(out, ref) <= tol
+        assert (lse.cpu() - lse_ref).abs().max() <= 2e-3
+
+    # fused query norm + rotation: the query fragments are transformed with the shipped kernel's
+    # arithmetic in the shipped order, so the two kernels see the same bf16 queries
+    B, S, H = 2, 700, 3
+    qkv = torch.randn(B, S, 3, H, D, generator=g(91)).bfloat16().to(device)
+    qd, kd, vd = qkv[:, :, 0], qkv[:, :, 1], _C.value_to_f16(qkv[:, :, 2])
+    w0 = (torch.rand(D, generator=g(92)) + 0.5).to(device)
+    w1 = (torch.rand(D, generator=g(93)) + 0.5).to(device)
+    ang = torch.rand(S, D // 2, generator=g(94)) * 6.28
+    cos, sin = ang.cos().contiguous().to(device), ang.sin().contiguous().to(device)
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MI355_ATTN_MFMA16", mode)
+        o = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=device)
+        _C.flash_attn_fwd(qd, kd, vd, o, None, D ** -0.5, v_is_f16=True, q_norm=(w0, w1, 100, 1e-6),
+                          q_rope=(cos, sin))
+        torch.cuda.synchronize()
+        outs.append(o.float())
+    assert rel_l2(outs[0], outs[1]) <= 1e-4
