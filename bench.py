@@ -386,10 +386,10 @@ def main():
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": None,
-                "kernel": {"fp8": "gemm_kernel<1,4,2,2,4,false,false,false> (fp8 W8A8 linear, "
-                                  "256x256x128B tile)",
-                           "bf16": "gemm_kernel<0,4,2,2,4,false,false,false> (bf16 linear, "
-                                   "256x256x128B tile)",
+                "kernel": {"fp8": "gemm_kernel<1,4,2,2,4,false,false,false,true,false> (fp8 W8A8 "
+                                  "linear, 256x256x128B tile, 16x16x128 MFMAs)",
+                           "bf16": "gemm_kernel<0,4,2,2,4,false,false,false,true,true> (bf16 linear, "
+                                   "256x256x128B tile, 16x16x32 MFMAs, pipelined K loop)",
                            "fp8-block": "gemm_kernel<1,4,2,2,4,true,false,false> (block-scaled fp8 "
                                         "linear, 256x256x128B tile)"}[args.mode],
                 "launches_per_step": d["n"] // nsteps_traced,
@@ -402,11 +402,14 @@ def main():
 
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
         # the profiler prints every template argument: <dtype, waves m, waves n, tm, tn, block
-        # scales, half output, fused key norm>; older summaries have the first six only
+        # scales, half output, fused key norm, 16x16 MFMA shapes, pipelined K loop>; older
+        # summaries have fewer of them (and the kernels of their time)
         key = {"fp8": "gemm_kernel<1, 4, 2, 2, 4, false", "bf16": "gemm_kernel<0, 4, 2, 2, 4, false",
                "fp8-block": "gemm_kernel<1, 4, 2, 2, 4, true"}[args.mode]
+        tail = {"fp8": ", false, false, true, false>", "bf16": ", false, false, true, true>",
+                "fp8-block": ", false, false, false, false>"}[args.mode]
         kernels = json.load(open(pmc))["kernels"]
-        name = next(k for k in (key + ">", key + ", false, false>") if k in kernels)
+        name = next(k for k in (key + tail, key + ">", key + ", false, false>") if k in kernels)
         roofline["traffic"] = kernels[name]["traffic_bytes_per_launch"]
         roofline["traffic_unit"] = "bytes per launch at the L2 memory side (2*FETCH_SIZE + WRITE_SIZE)"
         roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
