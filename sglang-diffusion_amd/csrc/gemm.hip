@@ -618,8 +618,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
     }
 
     if constexpr (PIPE) {
-      // Software-pipelined K loop (bf16; the fp8 form of it does not fit 256 registers beside the
-      // accumulators: 67 spills, not kept).  A K tile is walked in units of two weight
+      // Software-pipelined K loop (bf16 only: the fp8 forms of it that fit 256 registers beside the
+      // accumulators -- one activation set, re-read after a tile's last unit -- ran 1-7 % SLOWER
+      // than the plain loop and were removed).  A K tile is walked in units of two weight
       // fragments = 8 MFMAs; the fragments of unit u + 1 are requested from LDS
       // before the MFMAs of unit u are issued, and the wait + barrier that opens the NEXT K tile
       // sits inside the LAST unit of this one: by then every wave has all of this tile's
