@@ -128,7 +128,8 @@ __device__ __forceinline__ void load_q_fragments(const AttnParams& p, int b, int
 // D = head size (128 or 64).  KV tile = 64 keys.
 // F16: V holds IEEE half values and P is rounded to half (11 significant bits instead of
 // bf16's 8) before the PV product; Q, K and the output stay bf16.
-template <int D, bool TRREAD, bool F16, int NW = 4>
+// ASMV: the V fragment reads as inline asm (see the P.V phase).
+template <int D, bool TRREAD, bool F16, int NW = 4, bool ASMV = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
   constexpr int KV = 64;
   constexpr int ROWB = D * 2;                // bytes per K/V row
@@ -305,6 +306,23 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
       }
     }
     __builtin_amdgcn_s_setprio(0);
+    // (ASMV) the P.V phase's transposed V reads, see there.  (Requesting the first fragments
+    // here, ahead of the softmax, measured slower than requesting them where P.V starts.)
+    constexpr int PV_STEPS = 4 * DVB;  // (kb, st, d) steps of the P.V phase, one MFMA each
+    constexpr int PV_AHEAD = 3;        // steps whose fragments are in flight ahead of the MFMA
+    u32x2 tv[ASMV ? PV_STEPS : 1][2];
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    // (spelled as a macro: inline-asm operands inside a nested generic lambda do not compile)
+#define MI355_V_STEP_READ(II)                                                                     \
+  do {                                                                                            \
+    const int kb_ = (II) / (2 * DVB), st_ = ((II) / DVB) % 2, d_ = (II) % DVB;                    \
+    _Pragma("unroll") for (int half = 0; half < 2; ++half)                                        \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                        \
+                     : "=v"(tv[II][half])                                                         \
+                     : "v"(lds0 + (unsigned)vlane[d_][half]),                                     \
+                       "n"(cur * STAGE_BYTES + TILE_BYTES + (kb_ * 32 + st_ * 16) * ROWB)         \
+                     : "memory");                                                                 \
+  } while (0)
     // mask keys past the end (last tile only; wave-uniform branch)
     if (k0 + KV > p.Sk) {
 #pragma unroll
@@ -366,6 +384,43 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
     __builtin_amdgcn_s_setprio(2);
 
     // ---- O^T += V^T P^T ---------------------------------------------------------
+    if constexpr (TRREAD && ASMV) {
+      // The transposed reads as inline asm.  Through the builtin, the compiler cannot tell that
+      // these reads do not touch the stage the LDS-DMA of the NEXT tile is filling, and puts
+      // `s_waitcnt vmcnt(0)` in front of the first of them: the refill issued at the top of the
+      // tile then has to land before P.V may start instead of before the next tile does.  In
+      // asm the reads are invisible to that analysis; their waits are counted by hand (LDS
+      // operations return in order; no scalar loads are issued inside the tile loop).
+      constexpr int NIT = PV_STEPS, AHEAD = PV_AHEAD;
+#pragma unroll
+      for (int ii = 0; ii < AHEAD; ++ii) MI355_V_STEP_READ(ii);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (it + AHEAD < NIT) MI355_V_STEP_READ(it + AHEAD);
+        // reads of the steps it + 1 .. min(it + AHEAD, NIT - 1) may stay in flight
+        const int later = (it + AHEAD < NIT ? AHEAD : NIT - 1 - it) * 2;
+        if (later == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else if (later == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if (later == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if (later == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_assert(AHEAD <= 4, "the waits above");
+        __builtin_amdgcn_sched_barrier(0);
+        const int kb = it / (2 * DVB), st = (it / DVB) % 2, d = it % DVB;
+        if constexpr (F16) {
+          const f16x8 vf = __builtin_shufflevector(__builtin_bit_cast(f16x4, tv[it][0]),
+                                                   __builtin_bit_cast(f16x4, tv[it][1]), 0, 1, 2, 3,
+                                                   4, 5, 6, 7);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][st], oacc[d], 0, 0, 0);
+        } else {
+          const bf16x8 vf = __builtin_shufflevector(__builtin_bit_cast(bf16x4, tv[it][0]),
+                                                    __builtin_bit_cast(bf16x4, tv[it][1]), 0, 1, 2, 3,
+                                                    4, 5, 6, 7);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][st], oacc[d], 0, 0, 0);
+        }
+      }
+#undef MI355_V_STEP_READ
+    } else
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1223,7 +1278,7 @@ int launch_attn_pingpong(const AttnParams& p, hipStream_t st) {
 }
 
 // M16: attn_fwd16_kernel (the 16x16x32 MFMA shapes; head size 128) instead of attn_fwd_kernel
-template <int D, bool TRREAD, bool F16, int NW = 4, bool M16 = false>
+template <int D, bool TRREAD, bool F16, int NW = 4, bool M16 = false, bool ASMV = false>
 int launch_attn(const AttnParams& p, hipStream_t st) {
   if constexpr (NW == 4) {
     // Eight waves (256 query rows) share each K/V tile once the launch still has a workgroup
@@ -1238,7 +1293,7 @@ int launch_attn(const AttnParams& p, hipStream_t st) {
         n = 256;
       cus.store(n, std::memory_order_relaxed);
     }
-    if (((p.Sq + 255) / 256) * (int64_t)p.H * p.B >= n) return launch_attn<D, TRREAD, F16, 8, M16>(p, st);
+    if (((p.Sq + 255) / 256) * (int64_t)p.H * p.B >= n) return launch_attn<D, TRREAD, F16, 8, M16, ASMV>(p, st);
   }
   constexpr int LDS = 2 * 2 * 64 * D * 2;
   // the LDS limit is a per-device function attribute: remember which devices have it
@@ -1250,7 +1305,7 @@ int launch_attn(const AttnParams& p, hipStream_t st) {
   const unsigned long long dev_bit = 1ull << (dev & 63);
   void (*kfn)(AttnParams);
   if constexpr (M16) kfn = attn_fwd16_kernel<D, F16, NW>;
-  else kfn = attn_fwd_kernel<D, TRREAD, F16, NW>;
+  else kfn = attn_fwd_kernel<D, TRREAD, F16, NW, ASMV>;
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1337,6 +1392,12 @@ static int attn_entry(const void* q, const void* k, const void* v, void* out, fl
       return v_f16 ? launch_attn<128, true, true, 4, true>(p, st)
                    : launch_attn<128, true, false, 4, true>(p, st);
   }
+  // head size 128: the V fragment reads as inline asm (same bits, 1-1.5 % less time;
+  // MI355_ATTN_ASMV=0 selects the builtin form for A/B timing; read per call)
+  const char* asmv = getenv("MI355_ATTN_ASMV");
+  if (D == 128 && !(asmv && atoi(asmv) == 0))
+    return v_f16 ? launch_attn<128, true, true, 4, false, true>(p, st)
+                 : launch_attn<128, true, false, 4, false, true>(p, st);
   if (v_f16) return D == 128 ? launch_attn<128, true, true>(p, st) : launch_attn<64, true, true>(p, st);
   static const bool no_tr = getenv("MI355_ATTN_NO_TR") != nullptr;  // debugging aid
   if (no_tr)
