@@ -618,9 +618,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
     }
 
     if constexpr (PIPE) {
-      // Software-pipelined K loop (bf16 only: the fp8 forms of it that fit 256 registers beside the
-      // accumulators -- one activation set, re-read after a tile's last unit -- ran 1-7 % SLOWER
-      // than the plain loop and were removed).  A K tile is walked in units of two weight
+      // Software-pipelined K loop (bf16 only.  The fp8 forms of it that fit 256 registers beside
+      // the accumulators -- one activation set, re-read after a tile's last unit -- ran 1-7 %
+      // SLOWER than the plain loop, and with asm reads an fp8 operand, two 16-byte reads into
+      // ONE 8-register tuple, cannot be expressed: the copies it costs derail the schedule, 136
+      // spills.  Both removed.)  A K tile is walked in units of two weight
       // fragments = 8 MFMAs; the fragments of unit u + 1 are requested from LDS
       // before the MFMAs of unit u are issued, and the wait + barrier that opens the NEXT K tile
       // sits inside the LAST unit of this one: by then every wave has all of this tile's
@@ -632,52 +634,64 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
         if (p.ktiles > 1) stage(cur0 ^ 1);
       }
       {
+        // The fragment reads are inline asm with hand-counted waits: left to the compiler, every
+        // second unit waited with lgkmcnt(0) right after requesting the NEXT unit's fragments,
+        // i.e. for the reads it had just issued.  LDS operations return in order and no other
+        // LDS or scalar-memory operation is issued inside the K loop, so "all but the n youngest"
+        // is exact.  Every wait is followed by a sched_barrier: the compiler would otherwise move
+        // register-only MFMAs above it.
         constexpr int NIG = TN;      // units per K step (two 16-row weight fragments each)
         constexpr int NU = 2 * NIG;  // units per K tile (two K steps of 32)
         bf16x8 afb[2][2], bfb[2][TM * 2];
-        {
-          const unsigned char* xb = smem + (g & 1) * STAGE_BYTES + x_row_off16;
-          const unsigned char* wb = smem + (g & 1) * STAGE_BYTES + w_row_off16;
+        const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+#define MI355_LDS_READ(dst, addr, imm) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define MI355_LDS_WAIT(n)                                    \
+  do {                                                       \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                       \
+  } while (0)
+        unsigned xa0 = lds0 + (g & 1) * STAGE_BYTES + x_row_off16 + coff16_0;
+        unsigned xa1 = lds0 + (g & 1) * STAGE_BYTES + x_row_off16 + coff16_1;
+        unsigned wa0 = lds0 + (g & 1) * STAGE_BYTES + w_row_off16 + coff16_0;
+        unsigned wa1 = lds0 + (g & 1) * STAGE_BYTES + w_row_off16 + coff16_1;
 #pragma unroll
-          for (int j = 0; j < TM * 2; ++j)
-            bfb[0][j] = *reinterpret_cast<const bf16x8*>(xb + j * 16 * 128 + coff16_0);
+        for (int j = 0; j < TM * 2; ++j) MI355_LDS_READ(bfb[0][j], xa0, j * 16 * 128);
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
-            afb[0][a] = *reinterpret_cast<const bf16x8*>(wb + a * 16 * 128 + coff16_0);
-        }
+        for (int a = 0; a < 2; ++a) MI355_LDS_READ(afb[0][a], wa0, a * 16 * 128);
         for (int kt = 0; kt < p.ktiles; ++kt, ++g) {
-          const int cur = g & 1;
-          const unsigned char* xb = smem + cur * STAGE_BYTES + x_row_off16;
-          const unsigned char* wb = smem + cur * STAGE_BYTES + w_row_off16;
+          const bool turn = kt + 1 < p.ktiles;  // wave-uniform
 #pragma unroll
           for (int u = 0; u < NU; ++u) {
             const int ks = u / NIG, ig = u % NIG;
             if (u + 1 < NU) {
               const int ks1 = (u + 1) / NIG, ig1 = (u + 1) % NIG;
-              const int co1 = ks1 ? coff16_1 : coff16_0;
               if (ig1 == 0) {
 #pragma unroll
-                for (int j = 0; j < TM * 2; ++j)
-                  bfb[ks1][j] = *reinterpret_cast<const bf16x8*>(xb + j * 16 * 128 + co1);
+                for (int j = 0; j < TM * 2; ++j) MI355_LDS_READ(bfb[ks1][j], ks1 ? xa1 : xa0, j * 16 * 128);
               }
 #pragma unroll
               for (int a = 0; a < 2; ++a)
-                afb[(u + 1) & 1][a] =
-                    *reinterpret_cast<const bf16x8*>(wb + (2 * ig1 + a) * 16 * 128 + co1);
-            } else if (kt + 1 < p.ktiles) {
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MI355_LDS_READ(afb[(u + 1) & 1][a], ks1 ? wa1 : wa0, (2 * ig1 + a) * 16 * 128);
+              if (ig1 == 0) MI355_LDS_WAIT(TM * 2 + 2);
+              else MI355_LDS_WAIT(2);
+            } else if (turn) {
+              // every fragment of this K tile has to be in registers before the stage is refilled
+              asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
               __syncthreads();
-              if (kt + 2 < p.ktiles) stage(cur);
-              const unsigned char* xn = smem + (cur ^ 1) * STAGE_BYTES + x_row_off16;
-              const unsigned char* wn = smem + (cur ^ 1) * STAGE_BYTES + w_row_off16;
+              if (kt + 2 < p.ktiles) stage(g & 1);
+              xa0 ^= STAGE_BYTES;
+              xa1 ^= STAGE_BYTES;
+              wa0 ^= STAGE_BYTES;
+              wa1 ^= STAGE_BYTES;
 #pragma unroll
-              for (int j = 0; j < TM * 2; ++j)
-                bfb[0][j] = *reinterpret_cast<const bf16x8*>(xn + j * 16 * 128 + coff16_0);
+              for (int j = 0; j < TM * 2; ++j) MI355_LDS_READ(bfb[0][j], xa0, j * 16 * 128);
 #pragma unroll
-              for (int a = 0; a < 2; ++a)
-                afb[0][a] = *reinterpret_cast<const bf16x8*>(wn + a * 16 * 128 + coff16_0);
+              for (int a = 0; a < 2; ++a) MI355_LDS_READ(afb[0][a], wa0, a * 16 * 128);
+              __builtin_amdgcn_sched_barrier(0);
+            } else {
+              MI355_LDS_WAIT(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -687,6 +701,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#undef MI355_LDS_READ
+#undef MI355_LDS_WAIT
       }
     } else
     for (int kt = 0; kt < p.ktiles; ++kt, ++g) {
