@@ -286,7 +286,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
     // MFMA phases run at raised wave priority: when the SIMD's other wave is in its softmax, the
     // matrix unit is fed first (about 1 % at the Flux shape)
     __builtin_amdgcn_s_setprio(2);
-    {
+    if constexpr (ASMV) {
+      // K fragments by inline asm, two steps ahead, waits counted by hand (the compiler's own
+      // placement waits with lgkmcnt(0) right behind the reads it has just issued)
+      const unsigned lds0k = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+      bf16x8 kf[3][2];  // [step % 3][kb]
+#define MI355_K_READ(S)                                                                          \
+  _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                               \
+      asm volatile("ds_read_b128 %0, %1 offset:%2"                                               \
+                   : "=v"(kf[(S) % 3][kb])                                                       \
+                   : "v"(lds0k + (unsigned)koff[S]), "n"(cur * STAGE_BYTES + kb * 32 * ROWB)     \
+                   : "memory")
+      MI355_K_READ(0);
+      MI355_K_READ(1);
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        if (s + 2 < KSTEPS) MI355_K_READ(s + 2);
+        const int later = (s + 2 < KSTEPS ? 2 : KSTEPS - 1 - s) * 2;
+        if (later == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if (later == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s % 3][kb], qf[s], sacc[kb], 0, 0, 0);
+      }
+#undef MI355_K_READ
+    } else {
       bf16x8 kf[2][2];  // [parity of step][kb]
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
