@@ -620,9 +620,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
     if constexpr (PIPE) {
       // Software-pipelined K loop (bf16 only.  The fp8 forms of it that fit 256 registers beside
       // the accumulators -- one activation set, re-read after a tile's last unit -- ran 1-7 %
-      // SLOWER than the plain loop, and with asm reads an fp8 operand, two 16-byte reads into
-      // ONE 8-register tuple, cannot be expressed: the copies it costs derail the schedule, 136
-      // spills.  Both removed.)  A K tile is walked in units of two weight
+      // SLOWER than the plain loop.  With asm reads an fp8 operand is two 16-byte reads into ONE
+      // 8-register tuple: as two asm outputs the copies derail the schedule (136 spills); with
+      // each fragment in a FIXED tuple (the output constraint names the tuple, the instruction
+      // text its halves) and the MFMAs as volatile asm as well, the loop comes out exactly as
+      // written, same bits, and still 1-8 % slower at one unit of prefetch (18 spills) and
+      // 10-20 % slower at two (61 spills).  All removed.)  A K tile is walked in units of two weight
       // fragments = 8 MFMAs; the fragments of unit u + 1 are requested from LDS
       // before the MFMAs of unit u are issued, and the wait + barrier that opens the NEXT K tile
       // sits inside the LAST unit of this one: by then every wave has all of this tile's
