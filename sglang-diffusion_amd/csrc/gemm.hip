@@ -437,7 +437,10 @@ struct AccTile<true, TN, TM> {
 // use last is idle: the first K tile of the NEXT output tile is sent there by LDS-DMA before
 // the epilogue starts and lands underneath it, and the stage used last becomes the
 // epilogue's scratch (one 4-KiB slice per wave) and table area.
-// MF16: the 16x16 MFMA shapes instead of the 32x32 ones (plain per-token / bf16 form only).
+// MF16: the 16x16 MFMA shapes instead of the 32x32 ones (plain per-token / bf16 form only.  The
+// block-scaled form was built on v_mfma_scale_f32_16x16x128_f8f6f4 as well -- one MFMA from zero
+// per scale block, four multiply-adds to retire it -- and ran 1-5 % slower than the 32x32 form
+// below with units of two token blocks, 3-4 % with units of four: removed).
 template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE,
           bool OUT16 = false, bool KNORM = false, bool MF16 = false, bool PIPE = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
@@ -453,6 +456,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   constexpr int SCRATCH_WAVE = 32 * 128;
   constexpr int TABLE_OFF = NW * SCRATCH_WAVE;
   static_assert(TABLE_OFF + BN * 4 + BM * 4 + BN * 2 <= STAGE_BYTES, "scratch + tables fit a stage");
+  // block scales ride along with the operand stages: one K tile's BM activation scales and the
+  // weight-block scales of the tile's BN / 128 column blocks (a 64-lane slot), behind the stages
+  constexpr int SCALE_OFF = 2 * STAGE_BYTES;
+  constexpr int SCALE_STAGE = (BM + 64) * 4;
+  static_assert(!BLOCKSCALE || (NW > BM / 64 && BM % 64 == 0 && BN / 128 <= 64), "scale loader waves");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -483,6 +491,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
 
   // ---- per-lane LDS-DMA source pointers (advance 128 B per K tile) ---------
   const unsigned char* src[NPIECE];
+  const float* sc_src = nullptr;  // block scales: this lane's scale of the next K tile to stage
   auto set_src = [&](int m0, int n0) {
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
@@ -502,6 +511,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
         src[i] = p.w + gnrow * p.ldw_b + lc * 16;
       }
     }
+    if constexpr (BLOCKSCALE) {
+      // waves 0 .. BM/64 - 1: lane l fetches the scale of token wave * 64 + l (group scales live
+      // beside the activation rows: index by the mapped A row); wave BM/64: lane l the scale of
+      // the tile's l-th 128-channel block (clamped: the extra lanes repeat the last one)
+      if (wave < BM / 64) {
+        const int m = min(m0 + wave * 64 + lane, p.M - 1);
+        sc_src = p.sa + map_row32(m, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
+                                  p.a_map.row_offset) * p.sa_sm;
+      } else {
+        const int nb = min((n0 >> 7) + min(lane, BN / 128 - 1), (p.N - 1) >> 7);
+        sc_src = p.sb + nb * p.sb_sn;
+      }
+    }
   };
   auto stage = [&](int buf) {
 #pragma unroll
@@ -511,6 +533,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
                                        (lds_ptr_t)(smem + buf * STAGE_BYTES + piece * 1024), 16, 0,
                                        0);
       src[i] += 128;
+    }
+    if constexpr (BLOCKSCALE) {
+      // 4 bytes per lane, straight into LDS like the operands: no register waits for them, and
+      // the wait + barrier that opens a K tile covers them too
+      if (wave <= BM / 64) {
+        __builtin_amdgcn_global_load_lds(
+            (gbl_ptr_t)sc_src, (lds_ptr_t)(smem + SCALE_OFF + buf * SCALE_STAGE + wave * 256), 4, 0, 0);
+        sc_src += wave < BM / 64 ? p.sa_sk : p.sb_sk;
+      }
     }
   };
 
@@ -584,37 +615,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
 
-    // block-scaled variant: scale row pointers
-    const float* sa_row[TM];
-    float sa_cur[TM];  // this K tile's activation scales, fetched one tile ahead
-    const float* sb_col = nullptr;
-    float sb_cur = 1.f;
     // software pipeline of the block-scaled K loop: two partial tiles, and the scale of the
     // unit still waiting to be added (the last unit of the previous K tile)
     static_assert(!BLOCKSCALE || (TN * TM) % 2 == 0, "the last unit of a K tile uses part[1]");
+    // a wave's channels (TN * 32 <= 128, aligned) lie inside one 128-channel scale block
+    static_assert(!BLOCKSCALE || (TN * 32 <= 128 && 128 % (TN * 32) == 0),
+                  "one weight scale per wave and K tile");
     f32x16 part[2];
     float pend_f = 0.f;
     if constexpr (BLOCKSCALE) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) part[1][e] = 0.f;
-    }  // this K tile's weight-block scale, fetched one tile ahead as well
-    if constexpr (BLOCKSCALE) {
-      // a wave's channels (TN * 32 <= 128, aligned) lie inside one 128-channel scale block
-      static_assert(TN * 32 <= 128 && 128 % (TN * 32) == 0, "one weight scale per wave and K tile");
-      int nb = (n0 + wn * TN * 32) >> 7;
-      const int nb_max = (p.N - 1) >> 7;
-      if (nb > nb_max) nb = nb_max;
-      sb_col = p.sb + nb * p.sb_sn;
-      sb_cur = sb_col[0];
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        int m = m0 + wm * TM * 32 + j * 32 + r;
-        if (m >= p.M) m = p.M - 1;
-        // group scales live beside the activation rows: index by the mapped A row
-        sa_row[j] = p.sa + map_row32(m, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
-                                     p.a_map.row_offset) * p.sa_sm;
-        sa_cur[j] = sa_row[j][0];
-      }
     }
 
     if constexpr (PIPE) {
@@ -772,16 +783,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
         // waits for the scaling, and only two partial tiles exist (a second accumulator set
         // would not fit 2 waves per SIMD).  The last unit of a K tile is retired under the
         // first unit of the next one.
-        // The scales of the NEXT K tile are requested here and first read after the wait at
-        // the top of the next iteration: no memory wait inside the MFMA sequence.
+        // The K tile's scales were staged into LDS with its operands.
+        const float* sc_l = reinterpret_cast<const float*>(smem + SCALE_OFF + cur * SCALE_STAGE);
+        const float sbw = sc_l[BM + ((wn * TN * 32) >> 7)];
         float fa[TM];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) fa[j] = sa_cur[j] * sb_cur;
-        if (kt + 1 < p.ktiles) {
-#pragma unroll
-          for (int j = 0; j < TM; ++j) sa_cur[j] = sa_row[j][(int64_t)(kt + 1) * p.sa_sk];
-          sb_cur = sb_col[(int64_t)(kt + 1) * p.sb_sk];
-        }
+        for (int j = 0; j < TM; ++j) fa[j] = sc_l[wm * TM * 32 + j * 32 + r] * sbw;
         i32x8 xf[KSTEPS][TM];
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
@@ -1258,7 +1265,7 @@ template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS, bool OUT16 
           bool KNORM = false, bool MF16 = false, bool PIPE = false>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = 2 * (BM + BN) * 128 + (BS ? 2 * (BM + 64) * 4 : 0);
   // the LDS limit is a per-device function attribute: remember which devices have it
   // callers may launch from several host threads: the per-device flags are atomic (a lost
   // update would only repeat the attribute call)

@@ -1,6 +1,9 @@
 """A/B of one environment switch of the GEMM kernels on the Flux shapes, alternating in one
 process; the outputs of both settings are compared bit for bit first.
-python tools/gemm_env_ab.py VAR [A_VALUE B_VALUE]     ('-' = unset; default: unset against 1)"""
+python tools/gemm_env_ab.py VAR [A_VALUE B_VALUE [block]]     ('-' = unset; default: unset against 1)
+With `block` the block-scaled fp8 form runs instead (scales per token x 128 K and per 128 x 128 of
+the weight); there the two settings may sum a block's 128 products in another order, so the
+outputs are compared to one bf16 rounding step instead of bit for bit."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sglang-diffusion_amd"))
@@ -10,6 +13,7 @@ from sglang_diffusion_amd import _C
 dev = "cuda"
 var = sys.argv[1]
 vals = (sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ("-", "1")
+block = len(sys.argv) > 4 and sys.argv[4] == "block"
 
 
 def setv(v):
@@ -21,7 +25,12 @@ def setv(v):
 
 def operands(fp8, M, N, K):
     g = torch.Generator(device=dev).manual_seed(0)
-    if fp8:
+    if fp8 and block:
+        a = (torch.randn(M, K, device=dev, generator=g) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
+        w = (torch.randn(N, K, device=dev, generator=g) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
+        sa = torch.rand(M, K // 128, device=dev, generator=g) * 0.01
+        sb = torch.rand((N + 127) // 128, K // 128, device=dev, generator=g) * 0.01
+    elif fp8:
         a = (torch.randn(M, K, device=dev, generator=g) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
         w = (torch.randn(N, K, device=dev, generator=g) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
         sa = torch.rand(M, device=dev, generator=g) * 0.01
@@ -36,17 +45,25 @@ def operands(fp8, M, N, K):
 shapes = [(True, 16384, 9216, 3072), (True, 18432, 12288, 3072), (True, 18432, 3072, 15360),
           (True, 16384, 3072, 3072), (True, 2048, 9216, 3072), (True, 300, 264, 256), (False, 16384, 12288, 3072),
           (False, 16384, 3072, 12288), (False, 2048, 12288, 3072), (False, 1000, 520, 192)]
+if block:
+    shapes = [s for s in shapes if s[0]] + [(True, 130, 384, 1024)]
 bad = 0
 for fp8, M, N, K in shapes:
     a, w, sa, sb, bias = operands(fp8, M, N, K)
     outs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(2)]
-    call = lambda o: _C.linear_ex(a, w, o, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, sa=sa, sb=sb, bias=bias, fp8=fp8)
+    call = lambda o: _C.linear_ex(a, w, o, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, sa=sa, sb=sb, bias=bias, fp8=fp8,
+                                  block_scale=block)
     for i in range(2):
         setv(vals[i])
         call(outs[i])
     torch.cuda.synchronize()
     ndiff = (outs[0].view(torch.int16) != outs[1].view(torch.int16)).sum().item()
-    bad += ndiff
+    if block:
+        f0, f1 = outs[0].float(), outs[1].float()
+        step = ((f0 - f1).abs() / f0.abs().clamp_min(1e-30)).max().item()
+        bad += 0 if step <= 2 ** -7 * 1.01 and bool(torch.isfinite(f1).all()) else 1
+    else:
+        bad += ndiff
     res = [[], []]
     for rep in range(3):
         for i in range(2):
