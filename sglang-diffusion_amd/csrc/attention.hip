@@ -365,15 +365,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // Lazy running max: the reference point of the exponentials only has to be NEAR the row
     // maximum.  It moves (and O, l are rescaled) only when some row of the wave has outgrown
     // it by more than 2^LAZY_LOG2 in the exponent; until then p = 2^((s - m) c) may reach
     // 2^LAZY_LOG2 instead of 1, which fp32 sums and half / bf16 probabilities hold easily.
     // The softmax value is unchanged (numerator and denominator share the reference).
+    // The test runs on the lane's own 32 keys: a row (two lanes) has outgrown exactly when one
+    // of its lanes has, so the two halves are only exchanged (an LDS round trip) when the
+    // reference point does move.
     constexpr float LAZY_LOG2 = 8.0f;
     const bool outgrown = (mx - m_run) * c > LAZY_LOG2;  // true on the first tile (m_run = -inf)
     if (__builtin_amdgcn_ballot_w64(outgrown) != 0) {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
       m_run = m_new;
@@ -1126,9 +1129,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pingpong_kernel(AttnParams p)
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const bool outgrown = (mx - m_run) * c > LAZY_LOG2;
+    const bool outgrown = (mx - m_run) * c > LAZY_LOG2;  // per lane; exchanged only on a move
     if (__builtin_amdgcn_ballot_w64(outgrown) != 0) {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
       m_run = m_new;
