@@ -333,7 +333,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
     }
     __builtin_amdgcn_s_setprio(0);
     // (ASMV) the P.V phase's transposed V reads, see there.  (Requesting the first fragments
-    // here, ahead of the softmax, measured slower than requesting them where P.V starts.)
+    // here, ahead of the softmax, measured slower than requesting them where P.V starts -- and,
+    // once the softmax held no LDS exchange any more, the same to 0.2-0.5 %.)
     constexpr int PV_STEPS = 4 * DVB;  // (kb, st, d) steps of the P.V phase, one MFMA each
     constexpr int PV_AHEAD = 3;        // steps whose fragments are in flight ahead of the MFMA
     u32x2 tv[ASMV ? PV_STEPS : 1][2];
