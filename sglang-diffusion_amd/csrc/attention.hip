@@ -361,22 +361,34 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
         }
     }
     // ---- online softmax (query on the lane) -----------------------------------
-    float mx = sacc[0][0];
+    // Lazy reference point: the exponentials are taken against a reference m_run that only has
+    // to be NEAR the row maximum (numerator and denominator share it, the softmax value does not
+    // depend on it).  They are formed against the reference as it stands; it moves -- to the true
+    // row maximum, with O and l rescaled and the tile's exponentials redone -- only when a lane's
+    // sum of its 32 values is not <= LAZY_SUM = 2^13 (so every p that goes on is <= 2^13, which
+    // fp32 sums and half / bf16 probabilities hold easily; inf and NaN, i.e. the first tile with
+    // m_run = -inf, fail the test as well).  The row maximum itself (17 vector instructions per
+    // tile, and an LDS exchange between the two lanes of a row) is only computed when that happens.
+    constexpr float LAZY_SUM = 8192.0f;
+    float pe[2][16];
+    float rs;
+    auto exponentials = [&](float mc) {
+      rs = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
-    // Lazy running max: the reference point of the exponentials only has to be NEAR the row
-    // maximum.  It moves (and O, l are rescaled) only when some row of the wave has outgrown
-    // it by more than 2^LAZY_LOG2 in the exponent; until then p = 2^((s - m) c) may reach
-    // 2^LAZY_LOG2 instead of 1, which fp32 sums and half / bf16 probabilities hold easily.
-    // The softmax value is unchanged (numerator and denominator share the reference).
-    // The test runs on the lane's own 32 keys: a row (two lanes) has outgrown exactly when one
-    // of its lanes has, so the two halves are only exchanged (an LDS round trip) when the
-    // reference point does move.
-    constexpr float LAZY_LOG2 = 8.0f;
-    const bool outgrown = (mx - m_run) * c > LAZY_LOG2;  // true on the first tile (m_run = -inf)
-    if (__builtin_amdgcn_ballot_w64(outgrown) != 0) {
+        for (int e = 0; e < 16; ++e) {
+          pe[kb][e] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], c, -mc));
+          rs += pe[kb][e];
+        }
+    };
+    exponentials(m_run * c);
+    if (__builtin_amdgcn_ballot_w64(!(rs <= LAZY_SUM)) != 0) {
+      float mx = sacc[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -386,30 +398,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
       for (int d = 0; d < DVB; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+      exponentials(m_run * c);
     }
-    const float mc = m_run * c;
-    float rs = 0.f;
     typedef typename std::conditional<F16, f16x8, bf16x8>::type pfrag_t;
     pfrag_t pf[2][2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float pe[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        pe[e] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], c, -mc));
-        rs += pe[e];
-      }
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if constexpr (F16) {
-            pf[kb][st][j] = (_Float16)pe[8 * st + j];
+            pf[kb][st][j] = (_Float16)pe[kb][8 * st + j];
           } else {
-            pf[kb][st][j] = (__bf16)pe[8 * st + j];
+            pf[kb][st][j] = (__bf16)pe[kb][8 * st + j];
           }
         }
-    }
     l_run += rs;
     __builtin_amdgcn_s_setprio(2);
 
@@ -1038,7 +1042,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pingpong_kernel(AttnParams p)
   float m_run = -INFINITY;
   float l_run = 0.f;
   const float c = p.scale_log2;
-  constexpr float LAZY_LOG2 = 8.0f;
+  constexpr float LAZY_SUM = 8192.0f;
   const int ntiles = (p.Sk + KV - 1) / KV;
 
   auto v_frag = [&](const unsigned char* vt, int key0, int d) __attribute__((always_inline)) {
@@ -1125,13 +1129,26 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pingpong_kernel(AttnParams p)
           if (key >= p.Sk) sacc[kb][e] = -INFINITY;
         }
     }
-    float mx = sacc[0][0];
+    // (the sum test of attn_fwd_kernel's lazy reference point, same arithmetic in the same order)
+    float pe[2][16];
+    float rs;
+    auto exponentials = [&](float mc) {
+      rs = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
-    const bool outgrown = (mx - m_run) * c > LAZY_LOG2;  // per lane; exchanged only on a move
-    if (__builtin_amdgcn_ballot_w64(outgrown) != 0) {
+        for (int e = 0; e < 16; ++e) {
+          pe[kb][e] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], c, -mc));
+          rs += pe[kb][e];
+        }
+    };
+    exponentials(m_run * c);
+    if (__builtin_amdgcn_ballot_w64(!(rs <= LAZY_SUM)) != 0) {
+      float mx = sacc[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kb][e]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -1141,25 +1158,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pingpong_kernel(AttnParams p)
       for (int d = 0; d < DVB; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+      exponentials(m_run * c);
     }
-    const float mc = m_run * c;
-    float rs = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      float pe[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        pe[e] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], c, -mc));
-        rs += pe[e];
-      }
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if constexpr (F16) pf[kb][st][j] = (_Float16)pe[8 * st + j];
-          else pf[kb][st][j] = (__bf16)pe[8 * st + j];
+          if constexpr (F16) pf[kb][st][j] = (_Float16)pe[kb][8 * st + j];
+          else pf[kb][st][j] = (__bf16)pe[kb][8 * st + j];
         }
-    }
     l_run += rs;
   };
 
