@@ -369,6 +369,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(Attn
     // fp32 sums and half / bf16 probabilities hold easily; inf and NaN, i.e. the first tile with
     // m_run = -inf, fail the test as well).  The row maximum itself (17 vector instructions per
     // tile, and an LDS exchange between the two lanes of a row) is only computed when that happens.
+    // (Summing the ROUNDED half-precision probabilities two at a time with v_dot2c_f32_f16 against
+    // {1, 1} -- 16 instructions for the 32 adds -- measured 2.5 % slower: 906 -> 929 us.)
     constexpr float LAZY_SUM = 8192.0f;
     float pe[2][16];
     float rs;
