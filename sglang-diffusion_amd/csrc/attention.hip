@@ -793,52 +793,56 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd16_kernel(At
         }
     }
     // ---- online softmax ---------------------------------------------------------------
-    // Lazy reference point (see attn_fwd_kernel): it moves only when some lane's own scores
-    // have outgrown it by 2^LAZY_LOG2; only then is the row maximum taken across the four lanes
-    // of a row, so that they move to the same point.
-    constexpr float LAZY_LOG2 = 8.0f;
-    float mxl[2];
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-      mxl[jb] = sacc[0][jb][0];
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mxl[jb] = fmaxf(mxl[jb], sacc[kb][jb][e]);
-    }
-    const bool outgrown =
-        (mxl[0] - m_run[0]) * c > LAZY_LOG2 || (mxl[1] - m_run[1]) * c > LAZY_LOG2;
-    if (__builtin_amdgcn_ballot_w64(outgrown) != 0) {
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb) {
-        float mx = mxl[jb];
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[jb], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[jb] - m_new) * c);
-        m_run[jb] = m_new;
-        l_run[jb] *= alpha;
-#pragma unroll
-        for (int d = 0; d < DV16; ++d) oacc[d][jb] *= alpha;
-      }
-    }
+    // Lazy reference point with the sum test (see attn_fwd_kernel): the exponentials are formed
+    // against the reference as it stands; only when a lane's sum is not <= LAZY_SUM is the row
+    // maximum taken (across the four lanes of a row, so that they move to the same point) and
+    // the row's exponentials redone.
+    constexpr float LAZY_SUM = 8192.0f;
     typedef typename std::conditional<F16, f16x8, bf16x8>::type pfrag_t;
     pfrag_t pf[2][2];  // [kp][jb]
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+    float rs[2];
+    auto exponentials = [&](auto jbc) {
+      constexpr int jb = decltype(jbc)::value;
       const float mc = m_run[jb] * c;
-      float rs = 0.f;
+      rs[jb] = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float pe = __builtin_amdgcn_exp2f(fmaf(sacc[kb][jb][e], c, -mc));
-          rs += pe;
+          rs[jb] += pe;
           if constexpr (F16) pf[kb >> 1][jb][(kb & 1) * 4 + e] = (_Float16)pe;
           else pf[kb >> 1][jb][(kb & 1) * 4 + e] = (__bf16)pe;
         }
-      l_run[jb] += rs;
+    };
+    auto move_reference = [&](auto jbc) {
+      constexpr int jb = decltype(jbc)::value;
+      float mx = sacc[0][jb][0];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, sacc[kb][jb][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[jb], mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[jb] - m_new) * c);
+      m_run[jb] = m_new;
+      l_run[jb] *= alpha;
+#pragma unroll
+      for (int d = 0; d < DV16; ++d) oacc[d][jb] *= alpha;
+    };
+    constexpr std::integral_constant<int, 0> J0{};
+    constexpr std::integral_constant<int, 1> J1{};
+    exponentials(J0);
+    exponentials(J1);
+    if (__builtin_amdgcn_ballot_w64(!(rs[0] <= LAZY_SUM) || !(rs[1] <= LAZY_SUM)) != 0) {
+      move_reference(J0);
+      move_reference(J1);
+      exponentials(J0);
+      exponentials(J1);
     }
+    l_run[0] += rs[0];
+    l_run[1] += rs[1];
     __builtin_amdgcn_s_setprio(2);
 
     // ---- O^T += V^T P^T ---------------------------------------------------------------
