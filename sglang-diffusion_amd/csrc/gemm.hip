@@ -1289,6 +1289,10 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   // M tiles per XCD chunk of the tile walk: 8 for wide outputs; 2 for narrow ones (N <= 4096,
   // e.g. proj_out with K = 15360: 836 -> 793 us; measured with tools/gemm_probe.py narrow)
   q.group = tiles_n <= 16 ? 2 : 8;
+  if (const char* ge = getenv("MI355_GEMM_GROUP")) {  // A/B timing of the tile walk, read per call
+    const int gv = atoi(ge);
+    if (gv > 0 && tiles_n > 16) q.group = gv;
+  }
   dim3 grid((unsigned)min(nwg, resident_workgroups(LDS))), block(WAVES_M * WAVES_N * 64);
   hipLaunchKernelGGL(kfn, grid, block, LDS, st, q);
   MI355_CHECK_LAUNCH("gemm");
