@@ -342,6 +342,36 @@ def test_flash_attention_online_softmax_rescale(device):
     assert rel_l2(out[0, 17], ref[0, 17]) <= 1e-2
 
 
+@pytest.mark.parametrize("half_v", [False, True])
+def test_flash_attention_reference_moves_on_overflowing_sums(device, half_v):
+    """The reference point of the exponentials moves when a lane's sum of them is not <= 2^13.
+    Spikes whose exponentials overflow fp32 against the old reference (inf, and NaN beside masked
+    keys of a ragged last tile), spikes in every tile of some rows, and a plateau of scores that
+    sits just under the threshold for many tiles must all match the oracle."""
+    B, S, H, D = 1, 700, 2, 128  # 700 keys: the last 64-key tile is ragged
+    q = torch.randn(B, S, H, D, generator=g(91)).bfloat16()
+    k = torch.randn(B, S, H, D, generator=g(92)).bfloat16()
+    v = torch.randn(B, S, H, D, generator=g(93)).bfloat16()
+    k[0, 650, 0] = q[0, 5, 0] * 12       # scaled score ~135: 2^195 against the old reference -> inf
+    k[0, 699, 1] = q[0, 300, 1] * 12     # the same in the ragged tile, beside masked keys
+    for t in range(1, 10):               # row 40 of head 0: a growing spike in every tile
+        k[0, 64 * t + 7, 0] = q[0, 40, 0] * (0.5 * t)
+    # rows 100..131 of head 1: all keys from 128 on score ~ +5.4 (2^7.8) above the first tiles
+    u = q[0, 100:132, 1].float().mean(0)
+    u = u / u.norm()
+    k[0, 128:, 1] = (k[0, 128:, 1].float() + u * 6.0).bfloat16()
+    ref, lse_ref = ops.attention(q, k, v, return_lse=True)
+    out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=device)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=device)
+    fn = _C.attention if half_v else _C.flash_attn_fwd
+    fn(q.to(device), k.to(device), v.to(device), out, lse, D ** -0.5)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert rel_l2(out, ref) <= (1.5e-3 if half_v else 4e-3)
+    for (row, head) in ((5, 0), (300, 1), (40, 0), (110, 1)):
+        assert rel_l2(out[0, row, head], ref[0, row, head]) <= 1e-2, (row, head)
+    assert (lse.cpu() - lse_ref).abs().max() <= 2e-3
+
+
 def test_flash_attention_lazy_max_on_growing_scores(device):
     """Scores that climb steadily along the key axis: the running reference max lags behind
     the true max between rescales (probabilities above 1 in the meantime) and is moved
