@@ -127,24 +127,27 @@ __global__ __launch_bounds__(256) void fused_add_rmsnorm_kernel(unsigned short* 
 // -------------------------------------------------------- qk norm + rope ----
 // LPR lanes own one (token, head) row of D = 8*LPR elements.  Rows of q come
 // first, then rows of k.  Norm and rotation are both optional.
-template <int LPR>
+template <int LPR, int HPT = 1>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
     unsigned short* q, unsigned short* k, int64_t B, int64_t S, int64_t H, int64_t sb, int64_t ss,
     int64_t sh, const float* __restrict__ wq0, const float* __restrict__ wk0,
     const float* __restrict__ wq1, const float* __restrict__ wk1, int64_t s_split, float eps,
     const float* __restrict__ cosp, const float* __restrict__ sinp, int interleaved) {
   constexpr int D = 8 * LPR;
-  constexpr int RPB = 256 / LPR;  // rows per block
+  constexpr int RPB = 256 / LPR * HPT;  // rows per block
   const int sub = threadIdx.x % LPR;
   // 32-bit row arithmetic (the entry point checks 2*B*S*H < 2^31): 64-bit divisions would cost
   // more instructions than the rest of the thread's work
   const unsigned rows_one = (unsigned)(B * S * H);
-  const unsigned gr = blockIdx.x * (unsigned)RPB + threadIdx.x / LPR;
+  // A lane group handles HPT consecutive rows = HPT heads of ONE token (the launcher picks HPT
+  // as a divisor of H): their rotation-table row and norm weights are fetched once, and the HPT
+  // row loads are in flight together.
+  const unsigned gr = (blockIdx.x * (unsigned)(256 / LPR) + threadIdx.x / LPR) * HPT;
   // q == nullptr: only the key rows are processed (the query side is done by the attention
   // kernel as it loads Q)
   const unsigned rows_all = q ? 2 * rows_one : rows_one;
-  const bool live = gr < rows_all;
-  const unsigned g = live ? gr : rows_all - 1;
+  const bool live = gr < rows_all;  // rows_all is a multiple of HPT: all of a group's rows or none
+  const unsigned g = live ? gr : rows_all - HPT;
   const bool is_k = q ? g >= rows_one : true;
   const unsigned rrow = (q && is_k) ? g - rows_one : g;
   const unsigned tok = rrow / (unsigned)H;
@@ -153,53 +156,66 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
   const int64_t s = tok - bu * (unsigned)S;
   const int64_t b = bu;
   unsigned short* base = (is_k ? k : q) + b * sb + s * ss + hh * sh;
-  u32x4* p = reinterpret_cast<u32x4*>(base) + sub;
-  float f[8];
-  unpack8(*p, f);
+  u32x4 raw[HPT];
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) raw[i] = reinterpret_cast<const u32x4*>(base + i * sh)[sub];
   const float* wsel = is_k ? (s < s_split ? wk0 : wk1) : (s < s_split ? wq0 : wq1);
+  f32x4 wa = f32x4{0.f, 0.f, 0.f, 0.f}, wb = wa, c = wa, sn = wa, c1 = wa, s1 = wa;
   if (wsel) {
-    float sq = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sq += f[j] * f[j];
-    sq = group_sum<LPR>(sq);
-    const float rs = rsqrtf(sq / (float)D + eps);
-    const f32x4 wa = reinterpret_cast<const f32x4*>(wsel)[2 * sub];
-    const f32x4 wb = reinterpret_cast<const f32x4*>(wsel)[2 * sub + 1];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f[j] = rbf((f[j] * rs) * wa[j]);          // RMSNorm output is rounded to bf16 ...
-      f[4 + j] = rbf((f[4 + j] * rs) * wb[j]);  // ... before RoPE reads it
-    }
+    wa = reinterpret_cast<const f32x4*>(wsel)[2 * sub];
+    wb = reinterpret_cast<const f32x4*>(wsel)[2 * sub + 1];
   }
+  const bool lo = sub < LPR / 2;
   if (cosp) {
     if (interleaved) {
-      const f32x4 c = reinterpret_cast<const f32x4*>(cosp + s * (D / 2))[sub];
-      const f32x4 sn = reinterpret_cast<const f32x4*>(sinp + s * (D / 2))[sub];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float x1 = f[2 * j], x2 = f[2 * j + 1];
-        f[2 * j] = fmaf(-x2, sn[j], __fmul_rn(x1, c[j]));
-        f[2 * j + 1] = fmaf(x1, sn[j], __fmul_rn(x2, c[j]));
-      }
+      c = reinterpret_cast<const f32x4*>(cosp + s * (D / 2))[sub];
+      sn = reinterpret_cast<const f32x4*>(sinp + s * (D / 2))[sub];
     } else {
       // neox: element i pairs with i + D/2, held LPR/2 lanes away
-      const bool lo = sub < LPR / 2;
       const int cidx = (lo ? sub : sub - LPR / 2) * 8;
-      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cosp + s * (D / 2) + cidx);
-      const f32x4 c1 = *reinterpret_cast<const f32x4*>(cosp + s * (D / 2) + cidx + 4);
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sinp + s * (D / 2) + cidx);
-      const f32x4 s1 = *reinterpret_cast<const f32x4*>(sinp + s * (D / 2) + cidx + 4);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float other = __shfl_xor(f[j], LPR / 2, 64);
-        const float c = j < 4 ? c0[j] : c1[j - 4];
-        const float sn = j < 4 ? s0[j] : s1[j - 4];
-        // o1 = x1*cos - x2*sin ; o2 = x2*cos + x1*sin
-        f[j] = lo ? fmaf(-other, sn, __fmul_rn(f[j], c)) : fmaf(other, sn, __fmul_rn(f[j], c));
-      }
+      c = *reinterpret_cast<const f32x4*>(cosp + s * (D / 2) + cidx);
+      c1 = *reinterpret_cast<const f32x4*>(cosp + s * (D / 2) + cidx + 4);
+      sn = *reinterpret_cast<const f32x4*>(sinp + s * (D / 2) + cidx);
+      s1 = *reinterpret_cast<const f32x4*>(sinp + s * (D / 2) + cidx + 4);
     }
   }
-  if (live) *p = pack8(f);
+#pragma unroll
+  for (int i = 0; i < HPT; ++i) {
+    float f[8];
+    unpack8(raw[i], f);
+    if (wsel) {
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sq += f[j] * f[j];
+      sq = group_sum<LPR>(sq);
+      const float rs = rsqrtf(sq / (float)D + eps);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f[j] = rbf((f[j] * rs) * wa[j]);          // RMSNorm output is rounded to bf16 ...
+        f[4 + j] = rbf((f[4 + j] * rs) * wb[j]);  // ... before RoPE reads it
+      }
+    }
+    if (cosp) {
+      if (interleaved) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x1 = f[2 * j], x2 = f[2 * j + 1];
+          f[2 * j] = fmaf(-x2, sn[j], __fmul_rn(x1, c[j]));
+          f[2 * j + 1] = fmaf(x1, sn[j], __fmul_rn(x2, c[j]));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float other = __shfl_xor(f[j], LPR / 2, 64);
+          const float cc = j < 4 ? c[j] : c1[j - 4];
+          const float ss2 = j < 4 ? sn[j] : s1[j - 4];
+          // o1 = x1*cos - x2*sin ; o2 = x2*cos + x1*sin
+          f[j] = lo ? fmaf(-other, ss2, __fmul_rn(f[j], cc)) : fmaf(other, ss2, __fmul_rn(f[j], cc));
+        }
+      }
+    }
+    if (live) reinterpret_cast<u32x4*>(base + i * sh)[sub] = pack8(f);
+  }
 }
 
 // sgl_kernel::rotary_embedding semantics: positions-indexed [max_pos, rot_dim]
@@ -716,7 +732,14 @@ extern "C" int mi355_qk_norm_rope(void* q, void* k, int64_t B, int64_t S, int64_
   MI355_REQUIRE(rows < (1ll << 31), "qk_norm_rope: too many (token, head) rows");
   if (rows == 0) return MI355_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 128) {
+  // (eight heads per group measured 4 % slower than four: 39.9 against 38.4 us on the Flux key slice)
+  if (D == 128 && H % 4 == 0) {
+    // four heads of a token per lane group: one fetch of the token's rotation-table row for four
+    dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+    hipLaunchKernelGGL((qk_norm_rope_kernel<16, 4>), grid, block, 0, st, (unsigned short*)q,
+                       (unsigned short*)k, B, S, H, sb, ss, sh, wq0, wk0, wq1, wk1, s_split, eps,
+                       cos, sin, interleaved);
+  } else if (D == 128) {
     dim3 grid((unsigned)((rows + 15) / 16)), block(256);
     hipLaunchKernelGGL(qk_norm_rope_kernel<16>, grid, block, 0, st, (unsigned short*)q,
                        (unsigned short*)k, B, S, H, sb, ss, sh, wq0, wk0, wq1, wk1, s_split, eps,
