@@ -386,12 +386,12 @@ def main():
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": None,
-                "kernel": {"fp8": "gemm_kernel<1,4,2,2,4,false,false,false,true,false> (fp8 W8A8 "
+                "kernel": {"fp8": "gemm_kernel<1,4,2,2,4,false,false,true,false> (fp8 W8A8 "
                                   "linear, 256x256x128B tile, 16x16x128 MFMAs)",
-                           "bf16": "gemm_kernel<0,4,2,2,4,false,false,false,true,true> (bf16 linear, "
+                           "bf16": "gemm_kernel<0,4,2,2,4,false,false,true,true> (bf16 linear, "
                                    "256x256x128B tile, 16x16x32 MFMAs, pipelined K loop)",
-                           "fp8-block": "gemm_kernel<1,4,2,2,4,true,false,false> (block-scaled fp8 "
-                                        "linear, 256x256x128B tile)"}[args.mode],
+                           "fp8-block": "gemm_kernel<1,4,2,2,4,true,false,false,false> (block-scaled "
+                                        "fp8 linear, 256x256x128B tile)"}[args.mode],
                 "launches_per_step": d["n"] // nsteps_traced,
                 "avg_launch_us": d["ms"] * 1e3 / d["n"],
                 "flop_per_launch": d["flops"] / d["n"]}
@@ -402,14 +402,14 @@ def main():
 
         pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
         # the profiler prints every template argument: <dtype, waves m, waves n, tm, tn, block
-        # scales, half output, fused key norm, 16x16 MFMA shapes, pipelined K loop>; older
-        # summaries have fewer of them (and the kernels of their time)
+        # scales, half output, 16x16 MFMA shapes, pipelined K loop>; summaries taken before the
+        # fused-key-norm argument was withdrawn carry one more `false` in sixth place
         key = {"fp8": "gemm_kernel<1, 4, 2, 2, 4, false", "bf16": "gemm_kernel<0, 4, 2, 2, 4, false",
                "fp8-block": "gemm_kernel<1, 4, 2, 2, 4, true"}[args.mode]
-        tail = {"fp8": ", false, false, true, false>", "bf16": ", false, false, true, true>",
-                "fp8-block": ", false, false, false, false>"}[args.mode]
+        tail = {"fp8": ", false, true, false>", "bf16": ", false, true, true>",
+                "fp8-block": ", false, false, false>"}[args.mode]
         kernels = json.load(open(pmc))["kernels"]
-        name = next(k for k in (key + tail, key + ">", key + ", false, false>") if k in kernels)
+        name = next(k for k in (key + tail, key + ", false" + tail) if k in kernels)
         roofline["traffic"] = kernels[name]["traffic_bytes_per_launch"]
         roofline["traffic_unit"] = "bytes per launch at the L2 memory side (2*FETCH_SIZE + WRITE_SIZE)"
         roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
@@ -470,8 +470,9 @@ def main():
             import threading
 
             # rank 0 gives the job up after --c4-timeout and prints its line without it; a rank
-            # still waiting in a collective then would keep the launcher waiting for ever
-            dog = threading.Timer(args.c4_timeout + 30.0, lambda: os._exit(0))
+            # still waiting in a collective then would keep the launcher waiting for ever (exit
+            # code 3: the launcher and the driver must see the hang as a failure)
+            dog = threading.Timer(args.c4_timeout + 30.0, lambda: os._exit(3))
             dog.daemon = True
             dog.start()
             try:
@@ -526,7 +527,7 @@ def main():
         def give_up():
             out["c4"] = {"error": f"the CFG job did not finish within {args.c4_timeout} s"}
             print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)  # the headline line is out, but a hung job is a failure for the launcher
 
         dog = threading.Timer(args.c4_timeout, give_up)
         dog.daemon = True

@@ -47,8 +47,18 @@ const char* mi355_last_error(void);
  * 9: mi355_linear_args gained w_shuffled; mi355_linear_grouped, mi355_shuffle_weight and
  *    mi355_shuffled_weight_bytes were added.
  * 10: mi355_linear_args gained out_f16.
- * 11: mi355_linear_args gained kn_weight, kn_cos, kn_sin, kn_eps, kn_seq, kn_begin, kn_end. */
+ * 11: mi355_linear_args gained kn_weight, kn_cos, kn_sin, kn_eps, kn_seq, kn_begin, kn_end.
+ * 12: the entry points and fields of measured-slower variants were withdrawn: mi355_linear_args
+ *     lost w_shuffled and the seven kn_* fields (out_f16 is now its last field);
+ *     mi355_linear_grouped, mi355_shuffle_weight and mi355_shuffled_weight_bytes are gone.
+ *     mi355_reload_env was added. */
 int mi355_abi_version(void);
+
+/* The library reads its few MI355_* environment switches ONCE, when it is loaded (today:
+ * MI355_ATTN_ASMV=0 selects the compiler-scheduled LDS reads of the attention kernel instead of
+ * the hand-counted inline-asm ones; same results bit for bit).  This call reads them again, for
+ * tests that compare the two forms inside one process.  No counterpart in the reference. */
+void mi355_reload_env(void);
 
 /* ---------------------------------------------------------------- quant --
  * sgl_per_token_quant_fp8(Tensor input, Tensor! output_q, Tensor! output_s)
@@ -171,57 +181,14 @@ typedef struct {
    * that (activation, gate/residual, row maps, half columns) works as in the other modes. */
   int block_scale;
   int64_t sa_sm, sa_sk, sb_sk, sb_sn;
-  /* Optional: the same weight in MFMA-fragment order (mi355_shuffle_weight), or NULL.  With it
-   * (and N % 32 == 0, no block scales, a shape that takes 256 x 256 tiles) the weight operand
-   * CAN be loaded from global memory straight into registers, only the activations passing
-   * through LDS; results are bit-identical to the NULL case.  Measured 4-9 % slower than the
-   * LDS-staged weight on every Flux shape, so the path is taken only when the environment
-   * variable MI355_GEMM_WDIRECT is set (A/B timing); otherwise the field is ignored. */
-  const void* w_shuffled;
   /* Nonzero: out (and bias) are IEEE half instead of bf16 -- out_dtype = float16 of
    * fp8_scaled_mm / fp8_blockwise_scaled_mm (the reference's kernel test runs both dtypes,
    * sgl-kernel/tests/test_fp8_gemm.py:17-35).  fp32 accumulator x scales (+ bias) rounded once to
    * half (block scales: product rounded to half, then the half bias added).  fp8 modes only, no
    * activation / gate / residual / half-column range; the DiT itself is bf16 and never sets it. */
   int out_f16;
-  /* Optional (kn_weight != NULL): output columns [kn_begin, kn_end), heads of 128 channels, get
-   * the per-head RMSNorm (fp32 weight[128], eps) and -- with kn_cos / kn_sin fp32 [kn_seq, 64] --
-   * the interleaved rotary embedding of row (mapped output row) % kn_seq before they are stored:
-   * apply_qk_norm + apply_flashinfer_rope_qk_inplace on the key third of a fused q|k|v projection
-   * (runtime/models/dits/flux.py:356-393) without a pass of their own.  Bit-identical to this
-   * call without the fields followed by mi355_qk_norm_rope(q = NULL, k, ...) on those columns.
-   * bf16 or per-token fp8 mode, no activation / gate / residual / block scales, M > 16; the
-   * 256 x 256 tile class is used whatever the shape (a wave must hold a whole head).
-   * Measured on the Flux shapes: the separate pass costs 46.6 us, the same work in the
-   * projection's (exposed) epilogue adds about 90 us to it -- callers that can afford the
-   * separate pass should keep it; the fields serve callers that cannot launch one. */
-  const float* kn_weight;
-  const float* kn_cos;
-  const float* kn_sin;
-  float kn_eps;
-  int64_t kn_seq, kn_begin, kn_end;
 } mi355_linear_args;
 int mi355_linear_ex(const mi355_linear_args* args, void* stream);
-
-/* One or two mi355_linear_ex problems submitted together: the reference runs the text-stream
- * and the image-stream projections of a double block as separate linears
- * (models/dits/flux.py:182-205,401-413, mlp.py:94-113).  Each problem computes exactly what
- * mi355_linear_ex computes for it.  The pair shares ONE launch (a persistent grid walking the
- * output tiles of both) only on the register-fed weight kernel (both w_shuffled given, one
- * dtype, MI355_GEMM_WDIRECT set); otherwise the problems are launched one after the other,
- * which measured as fast: the image-stream problem fills whole rounds of the grid by itself. */
-int mi355_linear_grouped(const mi355_linear_args* args, int count, void* stream);
-
-/* Weight pre-shuffle for the register-fed weight path.  No counterpart in the reference (its
- * checkpoints keep [N, K] row-major weights, tools/convert_hf_to_fp8.py:48-79 and
- * layers/quantization/fp8.py:303-352; this runs once after loading and leaves the checkpoint
- * format alone).  out receives w[N, K] (row stride ldw elements; fp8 or bf16) as
- * [N/32][k-steps][fragment]: the 32-row x 64-byte (fp8) or 32-row x 16-element (bf16) A operand
- * of one MFMA, 16 bytes per lane, lanes in order.  N % 32 == 0, K bytes % 128 == 0;
- * mi355_shuffled_weight_bytes gives out's size (-1 for shapes that cannot be shuffled). */
-int64_t mi355_shuffled_weight_bytes(int64_t N, int64_t K, int fp8);
-int mi355_shuffle_weight(const void* w, void* out, int64_t N, int64_t K, int64_t ldw, int fp8,
-                         void* stream);
 
 /* ------------------------------------------------------------ attention --
  * Dense non-causal (or causal) softmax(Q K^T * scale) V, bf16 in/out, fp32

@@ -21,6 +21,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- host-side error plumbing -------------------------------------------
 void mi355_set_error(const char* fmt, ...);
+// MI355_ATTN_ASMV as read when the library was loaded (or at the last mi355_reload_env): nonzero
+// = the attention kernel's LDS fragment reads as inline asm with hand-counted waits (default)
+int mi355_env_attn_asmv();
 
 #define MI355_REQUIRE(cond, ...)          \
   do {                                    \

@@ -49,23 +49,7 @@ struct GemmParams {
   // block-scaled variant
   int64_t sa_sm, sa_sk, sb_sk, sb_sn;
   int group;  // M tiles per XCD chunk of the tile walk
-  // weight in MFMA-fragment order (mi355_shuffle_weight) and its k-steps per 32-row block
-  const unsigned char* wsh;
-  int wsh_ksteps;
   int out_f16;  // host side only: picks the instantiation whose output and bias are IEEE half
-  // per-head RMSNorm + interleaved rotation of output columns [kn_begin, kn_end) in the epilogue
-  const float* kn_w;
-  const float* kn_cos;
-  const float* kn_sin;
-  float kn_eps;
-  int kn_seq, kn_begin, kn_end;
-};
-
-// Up to two problems of one dtype walked by ONE persistent grid: the text-stream GEMM of a
-// double block rides in the image-stream launch instead of running alone on a worse tile.
-struct GroupParams {
-  GemmParams pr[2];
-  int nprob;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -81,14 +65,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // sb_l / sa_l / bias_l: the tile's per-channel scales, per-token scales and bias in LDS.
 // OUT16: the whole output (and the bias) is IEEE half, rounded once from fp32 -- out_dtype
 // float16 of the reference's fp8 GEMM ops; no gate / residual / half-column range in that mode.
-// KNORM: output columns [kn_begin, kn_end) are heads of 128 channels that get the per-head
-// RMSNorm and the interleaved rotary embedding of qk_norm_rope_kernel (elementwise.hip) before
-// they are stored -- the key third of a fused q|k|v projection.  A wave's TN * 32 = 128 columns
-// are exactly one head and a lane holds 64 channels of ONE row (the other 64 sit in the lane 32
-// away), so the row statistic is an in-lane sum plus two exchanges.  Same arithmetic in the
-// same order as the stand-alone kernel on the stored bf16 values, so both give the same bits.
-template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE, bool OUT16 = false,
-          bool KNORM = false>
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE, bool OUT16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM],
                                               unsigned char* scratch, const float* sb_l,
                                               const float* sa_l, const unsigned short* bias_l,
@@ -104,98 +81,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     float sam = 1.f;
     if constexpr (DT == 1 && !BLOCKSCALE) sam = sa_l[wm * TM * 32 + j * 32 + r];
     const int mw = m0 + wm * TM * 32 + j * 32;
-    bool normed = false;  // wave-uniform: this wave's head was finished in place below
-    if constexpr (KNORM) {
-      static_assert(TN == 4 && !BLOCKSCALE && !OUT16, "one head of 128 channels per wave");
-      const int head0 = n0 + wn * TN * 32;
-      if (head0 >= p.kn_begin && head0 < p.kn_end) {
-        normed = true;
-        // (1) the linear's bf16 result, in place, exactly as the plain path below forms it
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const int i = c >> 2, g = c & 3;
-          const int nl = wn * TN * 32 + i * 32 + 8 * g + 4 * h;
-          f32x4 sbv = f32x4{1.f, 1.f, 1.f, 1.f};
-          if constexpr (DT == 1) sbv = *reinterpret_cast<const f32x4*>(sb_l + nl);
-          const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
-          const f32x4 bsv =
-              f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
-                    __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[i][j][4 * g + e];
-            if constexpr (DT == 1) v = fmaf(v * sam, sbv[e], bsv[e]);  // as the plain path
-            else v += bsv[e];
-            acc[i][j][4 * g + e] = rbf(v);
-          }
-        }
-        // (2) sum of squares of the row: chunk c = channels 8c .. 8c+7 is summed element by
-        // element (this lane's four, continued by the partner's four), the 16 chunk sums by a
-        // butterfly over chunk-index bits 3, 2, 1, 0 -- the order of group_sum<16> over the 16
-        // lanes that hold one row in qk_norm_rope_kernel
-        auto partner = [&](float x) {
-          const unsigned int xb = __float_as_uint(x);
-          auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
-          return __uint_as_float(h ? sw[0] : sw[1]);
-        };
-        float cs[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const int i = c >> 2, g = c & 3;
-          float sq = 0.f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sq += acc[i][j][4 * g + e] * acc[i][j][4 * g + e];
-          // lanes h = 1 continue the chain the partner (elements 0..3 of the chunk) began
-          float sq2 = partner(sq);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sq2 += acc[i][j][4 * g + e] * acc[i][j][4 * g + e];
-          cs[c] = sq2;  // the chunk's sum in lanes h = 1
-        }
-#pragma unroll
-        for (int w = 8; w >= 1; w >>= 1)
-#pragma unroll
-          for (int c = 0; c < w; ++c) cs[c] = cs[c] + cs[c + w];
-        // (the exchange is its own statement: inside the ?: it would run with half the wave
-        // masked off and fetch nothing)
-        const float tot_partner = partner(cs[0]);
-        const float tot = h ? cs[0] : tot_partner;
-        const float rs = rsqrtf(tot / 128.0f + p.kn_eps);
-        // (3) weight, rounding, rotation
-        const int m = min(mw + r, p.M - 1);
-        const int64_t orow =
-            map_row32(m, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset);
-        const unsigned pos = (unsigned)orow % (unsigned)p.kn_seq;
-        const float* cosr = p.kn_cos ? p.kn_cos + (int64_t)pos * 64 : nullptr;
-        const float* sinr = p.kn_cos ? p.kn_sin + (int64_t)pos * 64 : nullptr;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const int i = c >> 2, g = c & 3;
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(p.kn_w + 8 * c + 4 * h);
-          float f[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) f[e] = rbf((acc[i][j][4 * g + e] * rs) * wv[e]);
-          if (cosr) {
-            const f32x2 cc = *reinterpret_cast<const f32x2*>(cosr + 4 * c + 2 * h);
-            const f32x2 sn = *reinterpret_cast<const f32x2*>(sinr + 4 * c + 2 * h);
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-              const float x1 = f[2 * q2], x2 = f[2 * q2 + 1];
-              f[2 * q2] = fmaf(-x2, sn[q2], __fmul_rn(x1, cc[q2]));
-              f[2 * q2 + 1] = fmaf(x1, sn[q2], __fmul_rn(x2, cc[q2]));
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = f[e];
-        }
-#ifdef KN_DEBUG_TOT
-        {
-          const unsigned int tb = __float_as_uint(tot);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[0][j][e] = (float)((tb >> (8 * e)) & 0xffu);
-        }
-#endif
-      }
-    }
 #pragma unroll
     for (int ip = 0; ip < TN / 2; ++ip) {
 #pragma unroll
@@ -214,10 +99,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
           if constexpr (DT == 1 && !BLOCKSCALE) sbv = *reinterpret_cast<const f32x4*>(sb_l + nl);
           const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
           f32x4 bsv;
-          if constexpr (KNORM) {
-            // a head finished above passes through: x * 1 * 1 + (-0) == x, zeros keep their sign
-            if (normed) sbv = f32x4{1.f, 1.f, 1.f, 1.f};
-          }
           if constexpr (OUT16) {
             auto hf = [](unsigned int bits) {
               return (float)__builtin_bit_cast(_Float16, (unsigned short)bits);
@@ -235,13 +116,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             // (python/sglang/srt/layers/quantization/fp8_utils.py:546-548)
             if constexpr (BLOCKSCALE && !OUT16) v = rbf(v);
             if constexpr (BLOCKSCALE && OUT16) v = (float)(_Float16)v;
-            const float be = (KNORM && normed) ? -0.0f : bsv[e];
             // per-token x per-channel scales and the bias: one multiply, one fused multiply-add
-            // (spelled out: the key-norm pass above must form the very same value)
             if constexpr (DT == 1 && !BLOCKSCALE)
-              v = fmaf(v * ((KNORM && normed) ? 1.f : sam), sbv[e], be);
+              v = fmaf(v * sam, sbv[e], bsv[e]);
             else
-              v += be;
+              v += bsv[e];
             y[e] = v;
           }
           if (p.act == MI355_ACT_GELU_TANH) {
@@ -442,9 +321,9 @@ struct AccTile<true, TN, TM> {
 // per scale block, four multiply-adds to retire it -- and ran 1-5 % slower than the 32x32 form
 // below with units of two token blocks, 3-4 % with units of four: removed).
 template <int DT /*0 bf16, 1 fp8*/, int WAVES_M, int WAVES_N, int TM, int TN, bool BLOCKSCALE,
-          bool OUT16 = false, bool KNORM = false, bool MF16 = false, bool PIPE = false>
+          bool OUT16 = false, bool MF16 = false, bool PIPE = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmParams p) {
-  static_assert(!MF16 || (!BLOCKSCALE && !OUT16 && !KNORM), "16x16 MFMAs: plain form only");
+  static_assert(!MF16 || (!BLOCKSCALE && !OUT16), "16x16 MFMAs: plain form only");
   static_assert(!PIPE || (MF16 && DT == 0), "pipelined K loop: bf16 on the 16x16 shape");
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = WAVES_M * TM * 32;
@@ -914,262 +793,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
       gemm_epilogue16<DT, WAVES_M, WAVES_N, TM, TN>(p, acc, area + wave * SCRATCH_WAVE, sb_l, sa_l,
                                                     bias_l, em0, en0, wave, lane);
     else
-      gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE, OUT16, KNORM>(
+      gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE, OUT16>(
           p, acc, area + wave * SCRATCH_WAVE, sb_l, sa_l, bias_l, em0, en0, wave, lane);
     if (!more) break;
     vb = nvb;
-  }
-}
-
-// ---- the weight operand straight from global memory into registers ---------------------
-// Same tile (256 x 256 x 128 B), same MFMAs in the same order (bit-identical results) as
-// gemm_kernel<DT, 4, 2, 2, 4>, but only the ACTIVATION tile goes through LDS.  The weight is
-// static: mi355_shuffle_weight stores it once in fragment order, [N/32][k-steps][64 lanes x 16 B
-// (x 2 for fp8)], so a wave's A operands of one K tile are two contiguous 4-KiB runs that it
-// loads with 16-byte-per-lane global loads one K tile ahead, into registers, with no barrier
-// in between.  That takes the weight's 32 KiB per K tile out of the LDS-DMA fill and its
-// 128 KiB per K tile out of the LDS reads (with both operands in LDS the LDS port is as busy
-// as the matrix pipe: 64 KiB written + 192 KiB read per 2048 MFMA clocks).  Waves are laid out
-// 2 (M) x 4 (N), 128 x 64 outputs each: a weight fragment is shared by two waves only, the
-// activation fragments (LDS) by four.
-template <int DT>
-__global__ __launch_bounds__(512, 2) void gemm_wdirect_kernel(GroupParams gp) {
-  constexpr int WAVES_M = 2, WAVES_N = 4, TM = 4, TN = 2, NW = 8;
-  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
-  constexpr int XSTAGE = BM * 128;
-  constexpr int NPIECE = BM / 8 / NW;  // 1-KiB LDS-DMA pieces per wave per K tile
-  constexpr int KSTEPS = DT == 0 ? 4 : 2;
-  constexpr int FRAG = DT == 0 ? 1024 : 2048;  // bytes of one (32 rows, k-step) fragment
-  constexpr int SCRATCH_WAVE = 32 * 128;
-  constexpr int EPI_OFF = 2 * XSTAGE;
-  constexpr int TABLE_OFF = EPI_OFF + NW * SCRATCH_WAVE;
-  typedef typename std::conditional<DT == 0, bf16x8, i32x8>::type wfrag_t;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave % WAVES_M;
-  const int wn = wave / WAVES_M;
-
-  const int nt0 = gp.pr[0].M > 0 ? ((gp.pr[0].M + BM - 1) / BM) * ((gp.pr[0].N + BN - 1) / BN) : 0;
-  const int nt1 = gp.nprob > 1 ? ((gp.pr[1].M + BM - 1) / BM) * ((gp.pr[1].N + BN - 1) / BN) : 0;
-  const int total = nt0 + nt1;
-
-  // Problem parameters are read from the kernel-argument segment where they are needed (tile
-  // boundaries only); nothing but the loop count stays live across the K loop.
-  auto tile_of = [&](const GemmParams& q, int vbl, int& m0, int& n0) {
-    const int tiles_m = (q.M + BM - 1) / BM, tiles_n = (q.N + BN - 1) / BN;
-    const int nwg = tiles_m * tiles_n;
-    const int qq = nwg >> 3, rr = nwg & 7, xcd = vbl & 7;
-    const int bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (vbl >> 3);
-    const int GROUP = q.group;
-    const int group_sz = GROUP * tiles_n;
-    const int gidx = bid / group_sz;
-    const int first_m = gidx * GROUP;
-    const int gm = min(tiles_m - first_m, GROUP);
-    const int in_g = bid - gidx * group_sz;
-    m0 = (first_m + in_g % gm) * BM;
-    n0 = (in_g / gm) * BN;
-  };
-
-  // activation rows: wave-uniform base (advances 128 B per K tile) + per-lane 32-bit offsets;
-  // weight fragments: wave-uniform bases (advance KSTEPS * FRAG per K tile) + lane * 16
-  const unsigned char* xbase = nullptr;
-  unsigned int xoff[NPIECE];
-  const unsigned char* wbase[TN];
-  const unsigned int woff = lane * 16;
-  auto set_src = [&](const GemmParams& q, int m0, int n0) {
-    xbase = q.a;
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-      const int piece = wave + i * NW;
-      const int row = piece * 8 + (lane >> 3);
-      const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      int gmrow = m0 + row;
-      if (gmrow >= q.M) gmrow = q.M - 1;
-      xoff[i] = (unsigned int)(map_row32(gmrow, (int)q.a_map.rows_per_batch, q.a_map.batch_rows,
-                                         q.a_map.row_offset) * q.lda_b + lc * 16);
-    }
-    const int nb_max = q.N / 32 - 1;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      int nb = (n0 + wn * TN * 32 + i * 32) >> 5;
-      if (nb > nb_max) nb = nb_max;
-      wbase[i] = q.wsh + (int64_t)nb * q.wsh_ksteps * FRAG;
-    }
-  };
-  auto stage_x = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-      const int piece = wave + i * NW;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xbase + xoff[i]),
-                                       (lds_ptr_t)(smem + buf * XSTAGE + piece * 1024), 16, 0, 0);
-    }
-    xbase += 128;
-  };
-  wfrag_t wf[2][TN][KSTEPS];
-  auto load_w = [&](auto setc) {
-    constexpr int set = decltype(setc)::value;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const unsigned char* wp = wbase[i] + woff;
-#pragma unroll
-      for (int s2 = 0; s2 < KSTEPS; ++s2) {
-        if constexpr (DT == 0) {
-          wf[set][i][s2] = *reinterpret_cast<const bf16x8*>(wp + s2 * FRAG);
-        } else {
-          const i32x4 lo = *reinterpret_cast<const i32x4*>(wp + s2 * FRAG);
-          const i32x4 hi = *reinterpret_cast<const i32x4*>(wp + s2 * FRAG + 1024);
-          wf[set][i][s2] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-      }
-      wbase[i] += KSTEPS * FRAG;
-    }
-  };
-
-  float sb_reg = 1.f, sa_reg = 1.f;
-  unsigned short bias_reg = 0;
-  auto load_tables = [&](const GemmParams& q, int m0, int n0) {
-    if (tid < BN) {
-      const int n = n0 + tid;
-      if constexpr (DT == 1) sb_reg = n < q.N ? q.sb[n] : 1.f;
-      bias_reg = (q.bias && n < q.N) ? q.bias[n] : (unsigned short)0;
-    }
-    if constexpr (DT == 1) {
-      if (tid < BM) {
-        const int mc = min(m0 + tid, q.M - 1);
-        sa_reg = q.sa[map_row32(mc, (int)q.a_map.rows_per_batch, q.a_map.batch_rows,
-                                q.a_map.row_offset)];
-      }
-    }
-  };
-
-  const int r = lane & 31;
-  const int h = lane >> 5;
-  const int swz = (r >> 1) & 7;
-  int coff[KSTEPS];
-#pragma unroll
-  for (int s2 = 0; s2 < KSTEPS; ++s2) {
-    const int c = DT == 0 ? (2 * s2 + h) : (4 * s2 + 2 * h);
-    coff[s2] = ((c ^ swz) << 4);
-  }
-  const int x_row_off = (wm * TM * 32 + r) * 128;
-  const int unit_scale = 0x7f7f7f7f;
-
-  int vb = blockIdx.x;
-  if (vb >= total) return;
-  int m0, n0, ktiles;
-  {
-    const GemmParams& q = gp.pr[vb >= nt0 ? 1 : 0];
-    tile_of(q, vb >= nt0 ? vb - nt0 : vb, m0, n0);
-    set_src(q, m0, n0);
-    load_tables(q, m0, n0);
-    ktiles = q.ktiles;
-  }
-  stage_x(0);
-  load_w(std::integral_constant<int, 0>{});
-
-  while (true) {
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // K tile kt computes from LDS stage SET and weight registers SET (compile time) while the
-    // other stage and register set fill
-    auto ktile = [&](auto setc, int kt) {
-      constexpr int cur = decltype(setc)::value;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < ktiles) {
-        stage_x(cur ^ 1);
-        load_w(std::integral_constant<int, cur ^ 1>{});
-      }
-      const unsigned char* sbase = smem + cur * XSTAGE + x_row_off;
-#pragma unroll
-      for (int s2 = 0; s2 < KSTEPS; ++s2) {
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          if constexpr (DT == 0) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sbase + j * 32 * 128 + coff[s2]);
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i][s2], xf, acc[i][j], 0,
-                                                                   0, 0);
-          } else {
-            const unsigned char* pb = sbase + j * 32 * 128;
-            const i32x4 lo = *reinterpret_cast<const i32x4*>(pb + coff[s2]);
-            const i32x4 hi = *reinterpret_cast<const i32x4*>(pb + (coff[s2] ^ 16));
-            const i32x8 xf = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                  wf[cur][i][s2], xf, acc[i][j], 0, 0, 0, unit_scale, 0, unit_scale);
-          }
-        }
-      }
-    };
-    for (int kt = 0; kt < ktiles; kt += 2) {
-      ktile(std::integral_constant<int, 0>{}, kt);
-      if (kt + 1 < ktiles) ktile(std::integral_constant<int, 1>{}, kt + 1);
-    }
-
-    // ---- tile done: park the tables, start the next tile's first K tile, run the epilogue --
-    __syncthreads();  // every wave is done reading the activation stages
-    float* sb_l = reinterpret_cast<float*>(smem + TABLE_OFF);
-    float* sa_l = sb_l + BN;
-    unsigned short* bias_l = reinterpret_cast<unsigned short*>(sa_l + BM);
-    if (tid < BN) {
-      sb_l[tid] = sb_reg;
-      bias_l[tid] = bias_reg;
-    }
-    if (tid < BM) sa_l[tid] = sa_reg;
-    const int em0 = m0, en0 = n0, evb = vb;
-    const int nvb = vb + (int)gridDim.x;
-    const bool more = nvb < total;
-    if (more) {
-      const GemmParams& nq = gp.pr[nvb >= nt0 ? 1 : 0];
-      tile_of(nq, nvb >= nt0 ? nvb - nt0 : nvb, m0, n0);
-      set_src(nq, m0, n0);
-      stage_x(0);  // lands under the epilogue
-      load_w(std::integral_constant<int, 0>{});
-      load_tables(nq, m0, n0);
-      ktiles = nq.ktiles;
-    }
-    __syncthreads();  // tables visible
-    gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, false>(
-        gp.pr[evb >= nt0 ? 1 : 0], acc, smem + EPI_OFF + wave * SCRATCH_WAVE, sb_l, sa_l, bias_l, em0,
-        en0, wave, lane);
-    if (!more) break;
-    vb = nvb;
-  }
-}
-
-// fragment-order copy of a weight [N, K] (row stride ldw_b bytes) for gemm_wdirect_kernel: one
-// thread per 16 bytes of the output
-template <int DT>
-__global__ __launch_bounds__(256) void shuffle_weight_kernel(const unsigned char* __restrict__ w,
-                                                             unsigned char* __restrict__ out,
-                                                             int64_t nblocks, int ksteps,
-                                                             int64_t ldw_b) {
-  constexpr int PER = DT == 0 ? 64 : 128;  // 16-B chunks per fragment
-  const int64_t total = nblocks * ksteps * PER;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % PER);
-    const int64_t f = i / PER;
-    const int ks = (int)(f % ksteps);
-    const int64_t nb = f / ksteps;
-    const int half = DT == 0 ? 0 : c >> 6, lane = c & 63;
-    const int rr = lane & 31, hh = lane >> 5;
-    // bf16: k elements 16 ks + 8 hh .. + 8; fp8: k bytes 64 ks + 32 hh + 16 half .. + 16
-    const int64_t kbyte = DT == 0 ? (int64_t)ks * 32 + hh * 16 : (int64_t)ks * 64 + hh * 32 + half * 16;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(w + (nb * 32 + rr) * ldw_b + kbyte);
-    *reinterpret_cast<u32x4*>(out + i * 16) = v;
   }
 }
 
@@ -1262,7 +889,7 @@ int resident_workgroups(int lds_bytes) {
 }
 
 template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, bool BS, bool OUT16 = false,
-          bool KNORM = false, bool MF16 = false, bool PIPE = false>
+          bool MF16 = false, bool PIPE = false>
 int launch_gemm(const GemmParams& p, hipStream_t st) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   constexpr int LDS = 2 * (BM + BN) * 128 + (BS ? 2 * (BM + 64) * 4 : 0);
@@ -1273,7 +900,7 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
-  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16, KNORM, MF16, PIPE>;
+  auto kfn = gemm_kernel<DT, WAVES_M, WAVES_N, TM, TN, BS, OUT16, MF16, PIPE>;
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1289,10 +916,6 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   // M tiles per XCD chunk of the tile walk: 8 for wide outputs; 2 for narrow ones (N <= 4096,
   // e.g. proj_out with K = 15360: 836 -> 793 us; measured with tools/gemm_probe.py narrow)
   q.group = tiles_n <= 16 ? 2 : 8;
-  if (const char* ge = getenv("MI355_GEMM_GROUP")) {  // A/B timing of the tile walk, read per call
-    const int gv = atoi(ge);
-    if (gv > 0 && tiles_n > 16) q.group = gv;
-  }
   dim3 grid((unsigned)min(nwg, resident_workgroups(LDS))), block(WAVES_M * WAVES_N * 64);
   hipLaunchKernelGGL(kfn, grid, block, LDS, st, q);
   MI355_CHECK_LAUNCH("gemm");
@@ -1330,6 +953,10 @@ int check_common(const mi355_linear_args* a, const char* who) {
   MI355_REQUIRE(a->f16_begin == a->f16_end || (!a->gate && (a->fp8 || a->M > 16)),
                 "%s: f16 output columns are not available with gate/residual or on the small-M path",
                 who);
+  MI355_REQUIRE(!a->out_f16 || (a->fp8 && !a->gate && !a->residual && a->act == MI355_ACT_NONE &&
+                                a->f16_begin == a->f16_end),
+                "%s: half output is built for the plain fp8 GEMMs (no activation, gate, residual "
+                "or half-column range)", who);
   return MI355_OK;
 }
 
@@ -1354,7 +981,6 @@ int build_params(const mi355_linear_args* a, GemmParams& p) {
   if (a->fp8) MI355_REQUIRE(a->sa && a->sb, "fp8 linear: scales missing");
   MI355_REQUIRE(!a->block_scale || (a->fp8 && a->K % 128 == 0),
                 "linear: block scales need the fp8 path and K %% 128 == 0");
-  MI355_REQUIRE(((uintptr_t)a->w_shuffled % 16) == 0, "linear: w_shuffled must be 16-byte aligned");
   p.a = (const unsigned char*)a->a;
   p.w = (const unsigned char*)a->w;
   p.sa = a->sa;
@@ -1389,79 +1015,7 @@ int build_params(const mi355_linear_args* a, GemmParams& p) {
     p.sb_sn = a->sb_sn;
   }
   p.group = ((a->N + 255) / 256) <= 16 ? 2 : 8;
-  p.wsh = (const unsigned char*)a->w_shuffled;
-  p.wsh_ksteps = (int)(kbytes / (a->fp8 ? 64 : 32));
   p.out_f16 = a->out_f16 ? 1 : 0;
-  p.kn_w = a->kn_weight;
-  p.kn_cos = a->kn_cos;
-  p.kn_sin = a->kn_sin;
-  p.kn_eps = a->kn_eps;
-  p.kn_seq = (int)a->kn_seq;
-  p.kn_begin = (int)a->kn_begin;
-  p.kn_end = (int)a->kn_end;
-  if (a->kn_weight) {
-    MI355_REQUIRE(!a->block_scale && !a->out_f16 && !a->gate && !a->residual &&
-                      a->act == MI355_ACT_NONE && a->M > 16,
-                  "linear: the fused key norm is built for the plain bf16 / per-token fp8 projection");
-    MI355_REQUIRE(a->kn_begin >= 0 && a->kn_begin % 128 == 0 && a->kn_end % 128 == 0 &&
-                      a->kn_end >= a->kn_begin && a->kn_end <= a->N,
-                  "linear: kn_begin/kn_end must be multiples of the head size 128 inside [0, N]");
-    MI355_REQUIRE((a->kn_cos == nullptr) == (a->kn_sin == nullptr) && a->kn_seq > 0 &&
-                      a->kn_seq < (1ll << 31),
-                  "linear: kn_cos / kn_sin come in pairs, kn_seq must be positive");
-    MI355_REQUIRE(((uintptr_t)a->kn_weight % 16) == 0 && ((uintptr_t)a->kn_cos % 8) == 0 &&
-                      ((uintptr_t)a->kn_sin % 8) == 0,
-                  "linear: kn_weight must be 16-byte, kn_cos / kn_sin 8-byte aligned");
-    // a half-column range may not overlap the normed heads
-    MI355_REQUIRE(a->f16_end <= a->kn_begin || a->f16_begin >= a->kn_end || a->f16_begin == a->f16_end,
-                  "linear: half columns and normed columns overlap");
-  }
-  MI355_REQUIRE(!a->out_f16 || (a->fp8 && !a->gate && !a->residual && a->act == MI355_ACT_NONE &&
-                                a->f16_begin == a->f16_end),
-                "linear: half output is built for the plain fp8 GEMMs (no activation, gate, residual "
-                "or half-column range)");
-  return MI355_OK;
-}
-
-// the register-fed weight path needs the fragment-order copy, whole 32-row blocks, and is built
-// for per-token x per-channel (or no) scales only
-bool wdirect_ok(const mi355_linear_args* a) {
-  // Measured 4-9 % SLOWER than the LDS-staged weight on every Flux shape (same bits): the fill
-  // path from L2, not the LDS port, bounds these GEMMs, and register-fed fragments are fetched
-  // by two waves each.  Kept for A/B timing only: MI355_GEMM_WDIRECT=1 turns it on.
-  const bool off = getenv("MI355_GEMM_WDIRECT") == nullptr;  // read per call: tests flip it
-  // per-lane activation offsets are 32-bit: the rows the operand can reach must lie within 4 GiB
-  const int64_t rows = a->a_map.rows_per_batch > 0
-                           ? ((a->M + a->a_map.rows_per_batch - 1) / a->a_map.rows_per_batch) *
-                                     a->a_map.batch_rows + a->a_map.row_offset
-                           : a->M;
-  const bool near = rows * a->lda * (a->fp8 ? 1 : 2) < (1ll << 32);
-  return !off && near && a->w_shuffled != nullptr && !a->block_scale && a->N % 32 == 0 && a->M > 16;
-}
-
-template <int DT>
-int launch_wdirect(const GroupParams& gp, hipStream_t st) {
-  constexpr int LDS = 2 * 256 * 128 + 8 * 32 * 128 + 256 * 4 + 256 * 4 + 256 * 2;
-  static std::atomic<unsigned long long> attr_devices{0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const unsigned long long dev_bit = 1ull << (dev & 63);
-  auto kfn = gemm_wdirect_kernel<DT>;
-  if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      mi355_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
-      return MI355_EHIP;
-    }
-    attr_devices.fetch_or(dev_bit, std::memory_order_release);
-  }
-  int64_t total = 0;
-  for (int i = 0; i < gp.nprob; ++i)
-    total += (int64_t)((gp.pr[i].M + 255) / 256) * ((gp.pr[i].N + 255) / 256);
-  dim3 grid((unsigned)std::min<int64_t>(total, resident_workgroups(LDS))), block(512);
-  hipLaunchKernelGGL(kfn, grid, block, LDS, st, gp);
-  MI355_CHECK_LAUNCH("gemm (register-fed weights)");
   return MI355_OK;
 }
 
@@ -1470,33 +1024,18 @@ int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hip
   if (p.out_f16)
     return block_scale ? launch_gemm<1, 2, 2, 2, 2, true, true>(p, st)
                        : launch_gemm<1, 2, 2, 2, 2, false, true>(p, st);
-  // the key-side norm + rotation needs a whole head per wave: the 256 x 256 class only
-  if (p.kn_w)
-    return fp8 ? launch_gemm<1, 4, 2, 2, 4, false, false, true>(p, st)
-               : launch_gemm<0, 4, 2, 2, 4, false, false, true>(p, st);
   if (block_scale)
     return big ? launch_gemm<1, 4, 2, 2, 4, true>(p, st) : launch_gemm<1, 2, 2, 2, 2, true>(p, st);
-  // The plain forms run on the 16x16 MFMA shapes: same bits as the 32x32 shapes (measured over
-  // every element of K = 15360 outputs) and 2-6 % (fp8) / 5-8 % (bf16) less time on the Flux
-  // shapes -- the chip is power-capped under these kernels and holds a higher clock with them.
-  // MI355_GEMM_MFMA16 (bit 0 bf16, bit 1 fp8; read per call) picks the shape for A/B timing.
-  const char* mf = getenv("MI355_GEMM_MFMA16");
-  const int mf16 = mf ? atoi(mf) : 3;
-  if (fp8) {
-    if (mf16 & 2)
-      return big ? launch_gemm<1, 4, 2, 2, 4, false, false, false, true>(p, st)
-                 : launch_gemm<1, 2, 2, 2, 2, false, false, false, true>(p, st);
-    return big ? launch_gemm<1, 4, 2, 2, 4, false>(p, st) : launch_gemm<1, 2, 2, 2, 2, false>(p, st);
-  }
-  // bf16: the software-pipelined K loop (same bits, 3-4 % less time; MI355_GEMM_PIPE=0 for A/B)
-  const char* pipe = getenv("MI355_GEMM_PIPE");
-  if ((mf16 & 1) && !(pipe && atoi(pipe) == 0))
-    return big ? launch_gemm<0, 4, 2, 2, 4, false, false, false, true, true>(p, st)
-               : launch_gemm<0, 2, 2, 2, 2, false, false, false, true, true>(p, st);
-  if (mf16 & 1)
-    return big ? launch_gemm<0, 4, 2, 2, 4, false, false, false, true>(p, st)
-               : launch_gemm<0, 2, 2, 2, 2, false, false, false, true>(p, st);
-  return big ? launch_gemm<0, 4, 2, 2, 4, false>(p, st) : launch_gemm<0, 2, 2, 2, 2, false>(p, st);
+  // The plain forms run on the 16x16 MFMA shapes (v_mfma_f32_16x16x32_bf16,
+  // v_mfma_scale_f32_16x16x128_f8f6f4): same bits as the 32x32 shapes (measured over every
+  // element of K = 15360 outputs) and 2-6 % (fp8) / 5-8 % (bf16) less time on the Flux shapes --
+  // the chip is power-capped under these kernels and holds a higher clock with them.  bf16 adds
+  // the software-pipelined K loop (same bits, 3-4 % less time).
+  if (fp8)
+    return big ? launch_gemm<1, 4, 2, 2, 4, false, false, true>(p, st)
+               : launch_gemm<1, 2, 2, 2, 2, false, false, true>(p, st);
+  return big ? launch_gemm<0, 4, 2, 2, 4, false, false, true, true>(p, st)
+             : launch_gemm<0, 2, 2, 2, 2, false, false, true, true>(p, st);
 }
 
 int launch_small_m(const mi355_linear_args* a, hipStream_t st) {
@@ -1541,82 +1080,12 @@ extern "C" int mi355_linear_ex(const mi355_linear_args* a, void* stream) {
   if (!a->fp8 && a->M <= 16 && a->a_map.rows_per_batch == 0 && a->o_map.rows_per_batch == 0 &&
       !a->gate)
     return launch_small_m(a, st);
-  GroupParams gp;
-  rc = build_params(a, gp.pr[0]);
+  GemmParams p;
+  rc = build_params(a, p);
   if (rc) return rc;
   // Tile choice: 256x256 (8 waves) when the grid still covers the chip, else 128x128.
   const bool big = use_big_tile(a->M, a->N, a->fp8 != 0);
-  if (big && wdirect_ok(a)) {
-    gp.pr[1] = gp.pr[0];
-    gp.nprob = 1;
-    return a->fp8 ? launch_wdirect<1>(gp, st) : launch_wdirect<0>(gp, st);
-  }
-  return dispatch_gemm(gp.pr[0], a->fp8 != 0, a->block_scale != 0, big, st);
-}
-
-// Measured (tools/gemm_wdirect_probe.py group, bench.py): sharing a launch buys nothing on the
-// Flux shapes -- the image-stream problem already fills whole rounds of the persistent grid, the
-// text-stream tiles only add a nearly empty extra round, and the text-stream problem alone runs
-// at 1.7 PF/s on 128 x 128 tiles.  The entry point stays (one launch on the register-fed kernel
-// when that is enabled, two launches otherwise); the engine launches the problems one by one.
-extern "C" int mi355_linear_grouped(const mi355_linear_args* args, int count, void* stream) {
-  MI355_REQUIRE(args != nullptr && count >= 1 && count <= 2,
-                "linear_grouped: one or two problems per launch");
-  if (count == 1) return mi355_linear_ex(args, stream);
-  bool one_launch = args[0].fp8 == args[1].fp8 && args[0].M > 16 && args[1].M > 16;
-  int64_t tb = 0;
-  for (int i = 0; i < 2; ++i) {
-    int rc = check_common(&args[i], "linear_grouped");
-    if (rc) return rc;
-    one_launch = one_launch && wdirect_ok(&args[i]);
-    tb += ((args[i].M + 255) / 256) * ((args[i].N + 255) / 256);
-  }
-  // together the problems must still cover the chip with 256 x 256 tiles
-  one_launch = one_launch && tb >= resident_workgroups(128 * 1024) * 3 / 4;
-  if (!one_launch) {
-    for (int i = 0; i < 2; ++i) {
-      int rc = mi355_linear_ex(&args[i], stream);
-      if (rc) return rc;
-    }
-    return MI355_OK;
-  }
-  GroupParams gp;
-  gp.nprob = 2;
-  for (int i = 0; i < 2; ++i) {
-    int rc = build_params(&args[i], gp.pr[i]);
-    if (rc) return rc;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  return args[0].fp8 ? launch_wdirect<1>(gp, st) : launch_wdirect<0>(gp, st);
-}
-
-extern "C" int64_t mi355_shuffled_weight_bytes(int64_t N, int64_t K, int fp8) {
-  if (N <= 0 || K <= 0 || N % 32 != 0 || (K * (fp8 ? 1 : 2)) % 128 != 0) return -1;
-  return N * K * (fp8 ? 1 : 2);
-}
-
-extern "C" int mi355_shuffle_weight(const void* w, void* out, int64_t N, int64_t K, int64_t ldw,
-                                    int fp8, void* stream) {
-  MI355_REQUIRE(w && out, "shuffle_weight: null pointer");
-  const int esz = fp8 ? 1 : 2;
-  MI355_REQUIRE(mi355_shuffled_weight_bytes(N, K, fp8) > 0,
-                "shuffle_weight: N (%ld) must be a multiple of 32 and K (%ld) of %d", (long)N,
-                (long)K, 128 / esz);
-  MI355_REQUIRE(((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0 && (ldw * esz) % 16 == 0,
-                "shuffle_weight: operands must be 16-byte aligned");
-  const int64_t nblocks = N / 32;
-  const int ksteps = (int)(K * esz / (fp8 ? 64 : 32));
-  const int64_t total = nblocks * ksteps * (fp8 ? 128 : 64);
-  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 1 << 20);
-  hipStream_t st = (hipStream_t)stream;
-  if (fp8)
-    hipLaunchKernelGGL(shuffle_weight_kernel<1>, dim3(grid), dim3(256), 0, st,
-                       (const unsigned char*)w, (unsigned char*)out, nblocks, ksteps, ldw * esz);
-  else
-    hipLaunchKernelGGL(shuffle_weight_kernel<0>, dim3(grid), dim3(256), 0, st,
-                       (const unsigned char*)w, (unsigned char*)out, nblocks, ksteps, ldw * esz);
-  MI355_CHECK_LAUNCH("shuffle_weight");
-  return MI355_OK;
+  return dispatch_gemm(p, a->fp8 != 0, a->block_scale != 0, big, st);
 }
 
 extern "C" int mi355_fp8_scaled_mm(const void* a, const void* b, const float* sa, const float* sb,

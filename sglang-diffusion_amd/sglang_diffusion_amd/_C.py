@@ -58,15 +58,7 @@ class LinearArgs(ctypes.Structure):
         ("sa_sk", _i64),
         ("sb_sk", _i64),
         ("sb_sn", _i64),
-        ("w_shuffled", _ptr),
         ("out_f16", _int),
-        ("kn_weight", _ptr),
-        ("kn_cos", _ptr),
-        ("kn_sin", _ptr),
-        ("kn_eps", _f32),
-        ("kn_seq", _i64),
-        ("kn_begin", _i64),
-        ("kn_end", _i64),
     ]
 
 
@@ -85,6 +77,7 @@ class AttnArgs(ctypes.Structure):
 SIGNATURES = {
     "mi355_last_error": (ctypes.c_char_p, []),
     "mi355_abi_version": (_int, []),
+    "mi355_reload_env": (None, []),
     "mi355_per_token_quant_fp8": (_int, [_ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr]),
     "mi355_per_token_group_quant_fp8": (
         _int,
@@ -101,9 +94,6 @@ SIGNATURES = {
     ),
     "mi355_linear_bf16": (_int, [_ptr, _ptr, _ptr, _ptr] + [_i64] * 6 + [_int, _ptr]),
     "mi355_linear_ex": (_int, [ctypes.POINTER(LinearArgs), _ptr]),
-    "mi355_linear_grouped": (_int, [ctypes.POINTER(LinearArgs), _int, _ptr]),
-    "mi355_shuffled_weight_bytes": (_i64, [_i64, _i64, _int]),
-    "mi355_shuffle_weight": (_int, [_ptr, _ptr, _i64, _i64, _i64, _int, _ptr]),
     "mi355_flash_attn_fwd": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
     "mi355_flash_attn_fwd_f16v": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
     "mi355_bf16_to_f16": (_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
@@ -156,7 +146,7 @@ _lib = None
 
 
 # the ABI revision these prototypes describe (mi355_abi_version() of the library must agree)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def load_library() -> ctypes.CDLL:
@@ -304,10 +294,9 @@ def linear_bf16(x, w, bias, out, act: int = 0) -> None:
 def _linear_args(
     a, w, out, *, M, N, K, lda, ldw, ldo, sa=None, sb=None, bias=None, residual=None, gate=None,
     ldg=0, gate_rows=0, a_map=None, o_map=None, fp8=False, act=0, f16_cols=None,
-    block_scale=False, w_shuffled=None, out_f16=False, k_norm=None,
-    into: Optional[LinearArgs] = None,
+    block_scale=False, out_f16=False,
 ) -> LinearArgs:
-    args = LinearArgs() if into is None else into
+    args = LinearArgs()
     args.a, args.w, args.out = a.data_ptr(), w.data_ptr(), out.data_ptr()
     args.sa, args.sb, args.bias = _p(sa), _p(sb), _p(bias)
     args.residual, args.gate = _p(residual), _p(gate)
@@ -324,52 +313,22 @@ def _linear_args(
         args.block_scale = 1
         args.sa_sm, args.sa_sk = sa.stride(0), sa.stride(1)
         args.sb_sn, args.sb_sk = sb.stride(0), sb.stride(1)
-    args.w_shuffled = _p(w_shuffled)
     args.out_f16 = int(bool(out_f16))
-    if k_norm is not None:
-        # (weight fp32 [128], eps, cos, sin fp32 [seq, 64] or None, seq, (col_begin, col_end))
-        kw_, eps, kcos, ksin, seq, cols = k_norm
-        args.kn_weight, args.kn_cos, args.kn_sin = kw_.data_ptr(), _p(kcos), _p(ksin)
-        args.kn_eps, args.kn_seq = float(eps), int(seq)
-        args.kn_begin, args.kn_end = cols
-    else:
-        args.kn_weight = None
     return args
 
 
 def linear_ex(a, w, out, **kw) -> None:
     """mi355_linear_ex; keyword arguments as _linear_args.  block_scale: `sa` is the [rows, K/128]
     group-scale tensor of the activations and `sb` the [N/128, K/128] block-scale tensor of the
-    weight (their strides are taken from the tensors).  w_shuffled: the weight in fragment order
-    (shuffle_weight), enabling the register-fed weight path."""
+    weight (their strides are taken from the tensors)."""
     args = _linear_args(a, w, out, **kw)
     _check(load_library().mi355_linear_ex(ctypes.byref(args), _stream(a)), "linear_ex")
 
 
-def linear_grouped(problems) -> None:
-    """One launch for one or two linear problems: `problems` is a list of (a, w, out, kwargs)
-    tuples with linear_ex's arguments."""
-    n = len(problems)
-    arr = (LinearArgs * n)()
-    for i, (a, w, out, kw) in enumerate(problems):
-        _linear_args(a, w, out, into=arr[i], **kw)
-    _check(load_library().mi355_linear_grouped(arr, n, _stream(problems[0][0])), "linear_grouped")
-
-
-def shuffle_weight(w: torch.Tensor) -> Optional[torch.Tensor]:
-    """The weight [N, K] (fp8 or bf16, K contiguous) in MFMA-fragment order for the register-fed
-    weight path, or None when its shape cannot be shuffled (N % 32, K bytes % 128)."""
-    N, K = w.shape
-    fp8 = w.dtype == torch.float8_e4m3fn
-    if not fp8 and w.dtype != torch.bfloat16:
-        raise TypeError(f"shuffle_weight: fp8 or bf16 weight expected, got {w.dtype}")
-    nbytes = load_library().mi355_shuffled_weight_bytes(N, K, int(fp8))
-    if nbytes < 0 or w.stride(1) != 1:
-        return None
-    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    _check(load_library().mi355_shuffle_weight(w.data_ptr(), out.data_ptr(), N, K, w.stride(0),
-                                               int(fp8), _stream(w)), "shuffle_weight")
-    return out
+def reload_env() -> None:
+    """Make the library read its MI355_* environment switches again (it reads them once, when
+    it is loaded); tests use it to compare kernel variants inside one process."""
+    load_library().mi355_reload_env()
 
 
 # ----------------------------------------------------------------- attention --

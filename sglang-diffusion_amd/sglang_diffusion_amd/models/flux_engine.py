@@ -185,11 +185,6 @@ class FluxEngine:
         # and probes fall back to one stream, where a launch's events mean something.
         # MI355_FLUX_OVERLAP_TEXT=0 turns it off.
         self.overlap_text = os.environ.get("MI355_FLUX_OVERLAP_TEXT", "1") == "1"
-        # key-side RMSNorm + rotation in the q|k|v projection's epilogue instead of its own pass:
-        # same bits, but measured SLOWER (the pass costs 2.65 ms per step, the epilogue work --
-        # exposed, two waves per SIMD, a gather of the rotation table -- adds 5.1 ms to the
-        # projections), so it is off unless MI355_FLUX_FUSE_K_NORM=1 (A/B timing)
-        self.fuse_k_norm = os.environ.get("MI355_FLUX_FUSE_K_NORM", "0") == "1"
         self._side_streams: Dict[str, torch.cuda.Stream] = {}
 
     def _side(self, dev) -> torch.cuda.Stream:
@@ -238,15 +233,14 @@ class FluxEngine:
 
     # ---------------------------------------------------------------------- helpers --
     def _prob(self, pk: _Packed, a, out, *, M, sa=None, a_map=None, o_map=None, residual=None,
-              gate=None, gate_rows=0, act=0, ldo=None, lda=None, f16_cols=None, k_norm=None):
+              gate=None, gate_rows=0, act=0, ldo=None, lda=None, f16_cols=None):
         """One quantised (or packed) projection as a linear problem: (kind, flops, bytes, a, w,
         out, kwargs of _C.linear_ex)."""
         kind = "gemm_fp8blk" if pk.block else "gemm_fp8" if pk.fp8 else "gemm_bf16"
         kw = dict(M=M, N=pk.N, K=pk.K, lda=lda or a.stride(0), ldw=pk.w.stride(0),
                   ldo=ldo or out.stride(0), sa=sa, sb=pk.s, bias=pk.b, residual=residual, gate=gate,
                   ldg=gate.stride(0) if gate is not None else 0, gate_rows=gate_rows, a_map=a_map,
-                  o_map=o_map, fp8=pk.fp8, act=act, f16_cols=f16_cols, block_scale=pk.block,
-                  k_norm=k_norm)
+                  o_map=o_map, fp8=pk.fp8, act=act, f16_cols=f16_cols, block_scale=pk.block)
         return (kind, 2.0 * M * pk.N * pk.K,
                 (M * pk.K + pk.N * pk.K) * (1 if pk.fp8 else 2) + 2.0 * M * pk.N, a, pk.w, out, kw)
 
@@ -262,7 +256,7 @@ class FluxEngine:
 
     def _launch(self, prob):
         kind, flops, nbytes, a, w, out, kw = prob
-        big = kw.get("k_norm") is not None or _uses_big_tile(kw["M"], kw["N"], kw["fp8"], a.device)
+        big = _uses_big_tile(kw["M"], kw["N"], kw["fp8"], a.device)
         self._run(kind + ("_256" if big else "_128"), flops, nbytes, _C.linear_ex, a, w, out, **kw)
 
     def _lin(self, pk: _Packed, a, out, **kw):
@@ -324,14 +318,6 @@ class FluxEngine:
         # once a value left half's range, see _C.VALUE_HALF)
         v_half = bool(_C.VALUE_HALF)
         vcols = (2 * D, 3 * D) if v_half else None
-        # key-side RMSNorm + rotation inside the q|k|v projection's epilogue (per-channel fp8 or
-        # bf16 projections on the 256 x 256 tile; a head = 128 channels): the stand-alone pass
-        # then only covers what those launches do not
-        fuse_k = self.fuse_k_norm and dh == 128 and not self.block and Mi > 16
-
-        def knorm(weight, eps):
-            return (weight, eps, cos, sin, S, (D, 2 * D)) if fuse_k else None
-
         if self.block:
             def quant(x, q, s_):  # per (token, 128 channels), fp8.py:303-352 on a block checkpoint
                 _C.per_token_group_quant_fp8(x, q, s_, 128, 1e-10, -448.0, 448.0, False)
@@ -383,21 +369,15 @@ class FluxEngine:
             a, sa = norm_in(blk["qkv"].fp8, chunk(oi, 0), chunk(oi, 1), Ti, map_i, Mi)
             with on_text_stream():
                 at, sat = norm_in(blk["add_qkv"].fp8, chunk(ot, 0), chunk(ot, 1), Tt, map_t, Mt, "_t")
-            pair(self._prob(blk["qkv"], a, qkv, M=Mi, sa=sa, o_map=map_i, f16_cols=vcols,
-                            k_norm=knorm(blk["nk"], blk["eps"])),
+            pair(self._prob(blk["qkv"], a, qkv, M=Mi, sa=sa, o_map=map_i, f16_cols=vcols),
                  self._prob(blk["add_qkv"], at, qkv, M=Mt, sa=sat, o_map=map_t, f16_cols=vcols))
             if side is not None:
                 main.wait_event(side.record_event())
-            # RMSNorm + RoPE: in place on k; the attention kernel does q's as it loads Q.  With
-            # the image rows done by their projection only the text rows are left (the text
-            # projection has too few rows for the tile class that can fuse it).
-            if fuse_k:
-                self._run("elementwise", 0.0, 4.0 * Mt * D, _C.qk_norm_rope, None, k[:, :Tt],
-                          blk["naq"], blk["nak"], blk["naq"], blk["nak"], Tt, blk["eps"], cos, sin,
-                          True)
-            else:
-                self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["naq"],
-                          blk["nak"], blk["nq"], blk["nk"], Tt, blk["eps"], cos, sin, True)
+            # RMSNorm + RoPE: in place on k; the attention kernel does q's as it loads Q.  (The
+            # key side inside the q|k|v projection's epilogue was built and measured: same bits,
+            # but the exposed epilogue work added 5.1 ms per step where this pass costs 2.65.)
+            self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["naq"],
+                      blk["nak"], blk["nq"], blk["nk"], Tt, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
                       attn4, None, scale, False, v_half,
                       q_norm=(blk["naq"], blk["nq"], Tt, blk["eps"]), q_rope=(cos, sin))
@@ -439,12 +419,10 @@ class FluxEngine:
             tell("before", "s", i)
             off = self.mod_off[("s", i)]
             a, sa = norm_in(blk["qkv"].fp8, chunk(off, 0), chunk(off, 1), S, None, Ms)
-            self._lin(blk["qkv"], a, qkv, M=Ms, sa=sa, f16_cols=vcols,
-                      k_norm=knorm(blk["nk"], blk["eps"]))
+            self._lin(blk["qkv"], a, qkv, M=Ms, sa=sa, f16_cols=vcols)
             self._lin(blk["mlp"], a, mlp_cols, M=Ms, sa=sa, act=1, ldo=catw)
-            if not fuse_k:
-                self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["nq"],
-                          blk["nk"], blk["nq"], blk["nk"], 0, blk["eps"], cos, sin, True)
+            self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["nq"],
+                      blk["nk"], blk["nq"], blk["nk"], 0, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
                       attn_in_cat, None, scale, False, v_half,
                       q_norm=(blk["nq"], blk["nq"], 0, blk["eps"]), q_rope=(cos, sin))

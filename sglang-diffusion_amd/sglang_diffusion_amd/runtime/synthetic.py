@@ -36,6 +36,55 @@ def init_synthetic_weights(model, seed: int = 0, host_rng: bool = True) -> None:
         p.data.copy_(w.to(p.dtype))
 
 
+def hashed_tensor(name: str, shape, seed: int, std: float, device="cpu",
+                  dtype=torch.bfloat16) -> torch.Tensor:
+    """A pseudo-random tensor that is a pure function of (name, seed, element index): integer
+    hashing and ONE fp32 multiply, so a CPU and a GPU produce the very same bits at any size
+    (torch.randn streams differ between devices, and 12 B host-side normal draws take minutes).
+    Each element is the sum of four 16-bit fields of two 32-bit hashes of its flat index (an
+    Irwin-Hall variate: bell-shaped, bounded at +-3.46 std), scaled to standard deviation `std`."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    M = 0xFFFFFFFF
+    out = torch.empty(n, dtype=dtype, device=device)
+    c = torch.tensor((3.0 ** 0.5) / 65536.0 * float(std), dtype=torch.float32, device=device)
+    key = _seed_for(name, seed)
+    step = 1 << 24                                   # bounded scratch: 16 M elements at a time
+
+    def mix(x):                                      # every product stays below 2^63
+        x = (((x >> 16) ^ x) * 0x45D9F3B) & M
+        x = (((x >> 16) ^ x) * 0x45D9F3B) & M
+        return (x >> 16) ^ x
+
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        idx = torch.arange(lo, hi, dtype=torch.int64, device=device)
+        h1 = mix((idx * 2 + key) & M)
+        h2 = mix((idx * 2 + 1 + key * 3) & M)
+        s = (h1 & 0xFFFF) + (h1 >> 16) + (h2 & 0xFFFF) + (h2 >> 16) - 2 * 65535
+        out[lo:hi] = (s.to(torch.float32) * c).to(dtype)
+    return out.view(*shape)
+
+
+def hashed_std(shape) -> float:
+    """The scale rule of init_synthetic_weights: fan_in^-0.5 for matrices, 0.02 for vectors."""
+    return float(shape[1]) ** -0.5 if len(shape) == 2 else 0.02
+
+
+@torch.no_grad()
+def init_hashed_weights(model, seed: int = 0) -> None:
+    """init_synthetic_weights with `hashed_tensor` draws: every device (and a CPU oracle that
+    calls hashed_tensor with the same names) gets bit-identical bf16 weights, generated where
+    the parameter lives.  Used where the FULL-SIZE network must exist on both sides."""
+    for name, p in model.named_parameters():
+        if p.dtype == torch.float32 and p.dim() == 1:  # RMSNorm weight
+            p.data.fill_(1.0)
+            continue
+        p.data.copy_(hashed_tensor(name, tuple(p.shape), seed, hashed_std(p.shape), p.device,
+                                   torch.bfloat16).to(p.dtype))
+
+
 @torch.no_grad()
 def init_synthetic_block_fp8(model, seed: int = 0, block=(128, 128)) -> None:
     """Fill a model built for an fp8-SERIALISED block-quantised checkpoint: every fp8 weight is

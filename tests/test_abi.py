@@ -34,7 +34,7 @@ def test_binding_table_matches_header():
 
 def test_error_reporting_without_gpu():
     lib = _C.load_library()
-    assert lib.mi355_abi_version() == _C.ABI_VERSION == 11
+    assert lib.mi355_abi_version() == _C.ABI_VERSION == 12
     # argument validation happens before any HIP call: a null pointer is rejected on the host
     rc = lib.mi355_per_token_quant_fp8(None, 4, 128, 128, None, None, None)
     assert rc == -1

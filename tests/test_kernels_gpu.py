@@ -541,27 +541,6 @@ def test_attention_workgroup_width_does_not_change_the_bits(device, D, half_v):
         assert torch.equal(lse_small, lse_big[b:b + 1, :2, lo:hi])
 
 
-@pytest.mark.parametrize("half_v", [True, False])
-@pytest.mark.parametrize("S", [1000, 64, 65, 191])
-def test_two_phase_attention_kernel_gives_the_same_bits(device, S, half_v, monkeypatch):
-    """The experimental two-phase kernel (MI355_ATTN_PINGPONG=1; slower, kept as a measured
-    result) does the shipped kernel's arithmetic in the shipped order: same output and LSE bits,
-    ragged last tile, one-tile and two-tile sequences included."""
-    B, H, D = 2, 3, 128
-    gen = torch.Generator(device=device).manual_seed(29)
-    q, k, v = ((torch.randn(B, S, H, D, generator=gen, device=device) * 1.3).bfloat16()
-               for _ in range(3))
-    vv = v.to(torch.float16) if half_v else v
-    out, lse = torch.empty_like(q), torch.empty(B, H, S, dtype=torch.float32, device=device)
-    _C.flash_attn_fwd(q, k, vv, out, lse, D ** -0.5, v_is_f16=half_v)
-    monkeypatch.setenv("MI355_ATTN_PINGPONG", "1")
-    out2, lse2 = torch.empty_like(q), torch.empty_like(lse)
-    _C.flash_attn_fwd(q, k, vv, out2, lse2, D ** -0.5, v_is_f16=half_v)
-    torch.cuda.synchronize()
-    assert torch.equal(out, out2)
-    assert torch.equal(lse, lse2)
-
-
 def test_attention_at_video_length(device):
     """One sequence-parallel rank's attention of the HunyuanVideo configuration (3 of 24 heads
     over 118 800 image + 256 text tokens): the merge property over a ragged key split, and
@@ -864,248 +843,47 @@ def test_empty_inputs_are_no_ops(device):
     torch.cuda.synchronize()
 
 
-# ------------------------------------------------------------ grouped / register-fed GEMMs --
-@pytest.mark.parametrize("fp8", [True, False])
-def test_grouped_linear_equals_two_launches(device, fp8, monkeypatch):
-    """mi355_linear_grouped: the image- and the text-stream problem of a double block in one
-    launch (row maps into a joint buffer, gate + residual epilogue, half-format columns) give
-    the very bits of two mi355_linear_ex launches; so does the register-fed weight path
-    (mi355_shuffle_weight + MI355_GEMM_WDIRECT=1), alone and grouped."""
-    from sglang_diffusion_amd import _C
-
-    B, Ti, Tt, K, N = 2, 2304, 200, 256, 512
-    S = Ti + Tt
-    g = torch.Generator(device=device).manual_seed(3)
-    rnd = lambda *s: torch.randn(*s, device=device, generator=g)  # noqa: E731
-    if fp8:
-        act = (rnd(B * S, K) * 50).clamp(-448, 448).to(torch.float8_e4m3fn)
-        ws = [(rnd(N, K) * 50).clamp(-448, 448).to(torch.float8_e4m3fn) for _ in range(2)]
-        sa = torch.rand(B * S, device=device, generator=g) * 0.01
-        sbs = [torch.rand(N, device=device, generator=g) * 0.01 for _ in range(2)]
-    else:
-        act = rnd(B * S, K).bfloat16()
-        ws = [(rnd(N, K) * 0.05).bfloat16() for _ in range(2)]
-        sa, sbs = None, [None, None]
-    biases = [rnd(N).bfloat16() for _ in range(2)]
-    gates = [rnd(B, N).bfloat16() for _ in range(2)]
-    resid = rnd(B * S, N).bfloat16()
-    maps = ((Ti, S, Tt), (Tt, S, 0))
-
-    def problems(out, shuffled, epilogue):
-        ps = []
-        for i, (T, mp) in enumerate(zip((Ti, Tt), maps)):
-            kw = dict(M=B * T, N=N, K=K, lda=K, ldw=K, ldo=N, sa=sa, sb=sbs[i], bias=biases[i],
-                      a_map=mp, o_map=mp, fp8=fp8)
-            if epilogue == "gate":
-                kw.update(residual=out, gate=gates[i], ldg=N, gate_rows=T)
-            else:
-                kw.update(f16_cols=(N // 2, N), act=1 if i == 0 else 0)
-            if shuffled:
-                kw["w_shuffled"] = _C.shuffle_weight(ws[i])
-            ps.append((act, ws[i], out, kw))
-        return ps
-
-    for epilogue in ("gate", "f16"):
-        want = resid.clone()
-        for a, w, o, kw in problems(want, False, epilogue):
-            _C.linear_ex(a, w, o, **kw)
-        got = resid.clone()
-        _C.linear_grouped(problems(got, False, epilogue))
-        assert torch.equal(got, want), epilogue
-        monkeypatch.setenv("MI355_GEMM_WDIRECT", "1")
-        got2, got3 = resid.clone(), resid.clone()
-        _C.linear_grouped(problems(got2, True, epilogue))
-        for a, w, o, kw in problems(got3, True, epilogue):
-            _C.linear_ex(a, w, o, **kw)
-        torch.cuda.synchronize()
-        monkeypatch.delenv("MI355_GEMM_WDIRECT")
-        assert torch.equal(got2, want) and torch.equal(got3, want), epilogue
-    # shapes that cannot be shuffled are reported, not mangled
-    assert _C.shuffle_weight(torch.zeros(40, 256, dtype=torch.bfloat16, device=device)) is None
-    # a pair that cannot share a launch (mixed dtypes) still computes both problems
-    x = rnd(64, 128).bfloat16()
-    w = rnd(32, 128).bfloat16()
-    o1, o2 = torch.zeros(64, 32, dtype=torch.bfloat16, device=device), torch.zeros(
-        64, 32, dtype=torch.bfloat16, device=device)
-    kw = dict(M=64, N=32, K=128, lda=128, ldw=128, ldo=32)
-    xq = (rnd(64, 128) * 20).to(torch.float8_e4m3fn)
-    wq = (rnd(32, 128) * 20).to(torch.float8_e4m3fn)
-    s1, s2 = torch.ones(64, device=device), torch.ones(32, device=device)
-    _C.linear_grouped([(x, w, o1, kw), (xq, wq, o2, dict(kw, fp8=True, sa=s1, sb=s2))])
-    r1, r2 = torch.empty_like(o1), torch.empty_like(o2)
-    _C.linear_ex(x, w, r1, **kw)
-    _C.linear_ex(xq, wq, r2, **dict(kw, fp8=True, sa=s1, sb=s2))
-    assert torch.equal(o1, r1) and torch.equal(o2, r2)
-
-
-@pytest.mark.parametrize("fp8", [True, False])
-@pytest.mark.parametrize("M,rows_per_batch,seq,off", [(640, 0, 320, 0), (300, 100, 164, 64),
-                                                       (257, 0, 4608, 0)])
-def test_linear_ex_fused_key_norm_equals_the_separate_pass(device, fp8, M, rows_per_batch, seq, off):
-    """q|k|v projection with the key heads normed and rotated in the epilogue == the same
-    projection followed by qk_norm_rope(q=None, k) on those columns, bit for bit: ragged M, an
-    output row map (the image rows of a joint buffer), V columns in half beside it."""
-    H, D, K = 3, 128, 256
-    N = 3 * H * D
-    gen = torch.Generator(device=device).manual_seed(31)
-    x = torch.randn(M, K, generator=gen, device=device).bfloat16()
-    w = (torch.randn(N, K, generator=gen, device=device) * K ** -0.5).bfloat16()
-    b = (torch.randn(N, generator=gen, device=device) * 0.1).bfloat16()
-    nw = (1.0 + 0.1 * torch.randn(D, generator=gen, device=device)).float()
-    ang = torch.rand(seq, D // 2, generator=gen, device=device) * 6.28
-    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
-    if rows_per_batch:
-        nb = M // rows_per_batch
-        o_map, rows_out = (rows_per_batch, seq, off), nb * seq
-    else:
-        nb, o_map, rows_out = M // seq if M % seq == 0 else 1, None, M
-    if fp8:
-        xq = torch.empty(M, K, dtype=FP8, device=device)
-        xs = torch.empty(M, dtype=torch.float32, device=device)
-        _C.per_token_quant_fp8(x, xq, xs)
-        wq, wsc = ops.quantize_weight_per_channel(w.cpu())
-        a_in, w_in, kw = xq, wq.to(device), dict(sa=xs, sb=wsc.to(device).float().contiguous(), fp8=True)
-    else:
-        a_in, w_in, kw = x, w, dict(fp8=False)
-    common = dict(M=M, N=N, K=K, lda=K, ldw=K, ldo=N, bias=b, o_map=o_map,
-                  f16_cols=(2 * H * D, 3 * H * D), **kw)
-    ref = torch.zeros(rows_out, N, dtype=torch.bfloat16, device=device)
-    _C.linear_ex(a_in, w_in, ref, **common)
-    fused = torch.zeros_like(ref)
-    _C.linear_ex(a_in, w_in, fused, k_norm=(nw, 1e-6, cos, sin, seq, (H * D, 2 * H * D)), **common)
-    # the separate pass on the rows the projection wrote
-    if rows_per_batch:
-        k_view = ref.view(nb, seq, 3, H, D)[:, off:off + rows_per_batch, 1]
-        _C.qk_norm_rope(None, k_view, nw, nw, nw, nw, 0, 1e-6, cos[off:], sin[off:], True)
-    elif M % seq == 0:
-        _C.qk_norm_rope(None, ref.view(nb, seq, 3, H, D)[:, :, 1], nw, nw, nw, nw, 0, 1e-6, cos, sin, True)
-    else:
-        _C.qk_norm_rope(None, ref.view(1, M, 3, H, D)[:, :, 1], nw, nw, nw, nw, 0, 1e-6, cos, sin, True)
-    torch.cuda.synchronize()
-    assert torch.equal(fused.view(torch.int16), ref.view(torch.int16))
-
-
-@pytest.mark.parametrize("fp8", [False, True])
-@pytest.mark.parametrize("M,N,K", [(300, 264, 256), (1000, 520, 192), (2048, 1536, 3072), (129, 8, 128)])
-def test_linear_mfma_shapes_and_pipelined_loop_give_the_same_bits(device, fp8, M, N, K, monkeypatch):
-    """The plain linears run on the 16x16 MFMA shapes (bf16: with the software-pipelined K
-    loop); MI355_GEMM_MFMA16=0 selects the 32x32 shapes and MI355_GEMM_PIPE=0 the plain loop.
-    All forms must give the same bits: ragged tiles, GELU epilogue, gate / residual through row
-    maps, half-format output columns."""
-    if fp8 and K % 128:
-        K = 256
-    x = torch.randn(M, K, generator=g(301)).bfloat16()
-    w = (torch.randn(N, K, generator=g(302)) * K ** -0.5).bfloat16()
-    b = (torch.randn(N, generator=g(303)) * 0.1).bfloat16()
-    gate = torch.randn(1, N, generator=g(304)).bfloat16().to(device)
-    res = torch.randn(M, N, generator=g(305)).bfloat16().to(device)
-    kw = {}
-    if fp8:
-        xq, xs = ops.per_token_quant_fp8(x)
-        wq, ws = ops.quantize_weight_per_channel(w)
-        a_d, w_d = xq.to(device), wq.to(device)
-        kw = dict(sa=xs.view(-1).to(device), sb=ws.to(device), fp8=True)
-    else:
-        a_d, w_d = x.to(device), w.to(device)
-    variants = [dict(bias=b.to(device)), dict(bias=b.to(device), act=1),
-                dict(bias=b.to(device), gate=gate, residual=True, ldg=N, gate_rows=M)]
-    if N % 32 == 0 and N >= 64:
-        variants.append(dict(bias=b.to(device), f16_cols=(N - 32, N)))
-
-    def run(v):
-        v = dict(v)
-        out = res.clone() if v.pop("residual", False) else torch.empty(M, N, dtype=torch.bfloat16, device=device)
-        if "gate" in v:
-            v["residual"] = out
-        _C.linear_ex(a_d, w_d, out, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, **v, **kw)
-        torch.cuda.synchronize()
-        return out
-
-    for v in variants:
-        base = run(v)
-        for env in ({"MI355_GEMM_MFMA16": "0"}, {"MI355_GEMM_PIPE": "0"}):
-            for k_, val in env.items():
-                monkeypatch.setenv(k_, val)
-            other = run(v)
-            for k_ in env:
-                monkeypatch.delenv(k_)
-            assert torch.equal(base.view(torch.int16), other.view(torch.int16)), (env, sorted(v))
-
-
+# ----------------------------------------------------------------- switches and guards --
 @pytest.mark.parametrize("half_v", [True, False])
-@pytest.mark.parametrize("B,Sq,Sk,H,Hk", [(1, 64, 64, 2, 2), (2, 300, 333, 4, 2), (2, 257, 129, 2, 1),
-                                           (1, 31, 1, 2, 2), (1, 700, 1100, 3, 3)])
-def test_attention_on_the_small_mfma_shape_vs_oracle(device, B, Sq, Sk, H, Hk, half_v, monkeypatch):
-    """attn_fwd16_kernel (MI355_ATTN_MFMA16=1: the 16x16x32 MFMA shapes, four lanes per query row)
-    against the oracle at the shipped kernel's tolerances: ragged query / key tiles, grouped
-    heads, both P.V precisions, output and LSE."""
+@pytest.mark.parametrize("B,S,Sk,H", [(1, 200, 333, 2),      # 128-row workgroups, ragged last tile
+                                      (4, 1000, 1000, 24),   # 256-row workgroups (a workgroup per CU)
+                                      (1, 64, 1, 1), (2, 257, 129, 3)])
+def test_attention_asm_reads_and_builtin_reads_give_the_same_bits(device, B, S, Sk, H, half_v,
+                                                                 monkeypatch):
+    """Head size 128 reads its K and V fragments from LDS with inline asm and hand-counted waits
+    by default; MI355_ATTN_ASMV=0 (read when the library is loaded; `reload_env` re-reads it)
+    selects the compiler-scheduled builtin reads.  Both forms must produce the same output and
+    log-sum-exp bits on both workgroup widths, both P.V precisions and ragged key counts."""
     D = 128
-    q = torch.randn(B, Sq, H, D, generator=g(311)).bfloat16()
-    k = torch.randn(B, Sk, Hk, D, generator=g(312)).bfloat16()
-    v = torch.randn(B, Sk, Hk, D, generator=g(313)).bfloat16()
-    kk, vv = k.repeat_interleave(H // Hk, 2), v.repeat_interleave(H // Hk, 2)
-    ref, lse_ref = ops.attention(q, kk, vv, return_lse=True)
-    monkeypatch.setenv("MI355_ATTN_MFMA16", "1")
-    out = torch.full((B, Sq, H, D), float("nan"), dtype=torch.bfloat16, device=device)
-    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=device)
-    vd = v.to(device)
-    _C.flash_attn_fwd(q.to(device), k.to(device), _C.value_to_f16(vd) if half_v else vd, out, lse,
-                      D ** -0.5, v_is_f16=half_v)
-    torch.cuda.synchronize()
-    assert torch.isfinite(out.float()).all()
-    assert rel_l2(out, ref) <= (1e-3 if half_v else 4e-3)
-    assert (lse.cpu() - lse_ref).abs().max() <= 2e-3
-
-
-def test_attention_on_the_small_mfma_shape_moves_its_reference_point(device, monkeypatch):
-    """The 16x16 kernel takes the cross-lane row maximum only when some lane's own scores have
-    outgrown the reference point: a spike late in the key sequence (one lane of one row sees it)
-    and steadily climbing scores (the point moves several times, probabilities above 1 in
-    between) must both match the oracle, and the fused query norm + rotation must match the
-    shipped kernel's."""
-    monkeypatch.setenv("MI355_ATTN_MFMA16", "1")
-    B, S, H, D = 1, 256, 1, 128
-    q = torch.randn(B, S, H, D, generator=g(44)).bfloat16()
-    k = torch.randn(B, S, H, D, generator=g(45)).bfloat16()
-    v = torch.randn(B, S, H, D, generator=g(46)).bfloat16()
-    k[0, 200, 0] = q[0, 17, 0] * 4
-    ref = ops.attention(q, k, v)
-    out = torch.empty_like(q, device=device)
-    _C.flash_attn_fwd(q.to(device), k.to(device), v.to(device), out, None, D ** -0.5)
-    assert rel_l2(out, ref) <= 4e-3
-    assert rel_l2(out[0, 17], ref[0, 17]) <= 1e-2
-
-    B, S, H = 1, 1024, 2
-    q = torch.randn(B, S, H, D, generator=g(81)).bfloat16()
-    k = torch.randn(B, S, H, D, generator=g(82)).bfloat16() * 0.3
-    v = torch.randn(B, S, H, D, generator=g(83)).bfloat16()
-    u = q.float().mean(dim=1, keepdim=True)
-    u = u / u.norm(dim=-1, keepdim=True)
-    k = (k.float() + torch.linspace(0, 1, S).view(1, S, 1, 1) * u * 40.0).bfloat16()
-    ref, lse_ref = ops.attention(q, k, v, return_lse=True)
-    for fn, tol in ((_C.flash_attn_fwd, 4e-3), (_C.attention, 1.5e-3)):
-        out = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=device)
-        lse = torch.empty(B, H, S, dtype=torch.float32, device=device)
-        fn(q.to(device), k.to(device), v.to(device), out, lse, D ** -0.5)
-        assert torch.isfinite(out.float()).all()
-        assert rel_l2(out, ref) <= tol
-        assert (lse.cpu() - lse_ref).abs().max() <= 2e-3
-
-    # fused query norm + rotation: the query fragments are transformed with the shipped kernel's
-    # arithmetic in the shipped order, so the two kernels see the same bf16 queries
-    B, S, H = 2, 700, 3
-    qkv = torch.randn(B, S, 3, H, D, generator=g(91)).bfloat16().to(device)
-    qd, kd, vd = qkv[:, :, 0], qkv[:, :, 1], _C.value_to_f16(qkv[:, :, 2])
-    w0 = (torch.rand(D, generator=g(92)) + 0.5).to(device)
-    w1 = (torch.rand(D, generator=g(93)) + 0.5).to(device)
-    ang = torch.rand(S, D // 2, generator=g(94)) * 6.28
-    cos, sin = ang.cos().contiguous().to(device), ang.sin().contiguous().to(device)
+    gen = torch.Generator(device=device).manual_seed(41)
+    q = (torch.randn(B, S, H, D, generator=gen, device=device) * 1.3).bfloat16()
+    k = (torch.randn(B, Sk, H, D, generator=gen, device=device) * 1.3).bfloat16()
+    v = (torch.randn(B, Sk, H, D, generator=gen, device=device) * 1.3).bfloat16()
+    vv = v.to(torch.float16) if half_v else v
     outs = []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MI355_ATTN_MFMA16", mode)
-        o = torch.empty(B, S, H, D, dtype=torch.bfloat16, device=device)
-        _C.flash_attn_fwd(qd, kd, vd, o, None, D ** -0.5, v_is_f16=True, q_norm=(w0, w1, 100, 1e-6),
-                          q_rope=(cos, sin))
-        torch.cuda.synchronize()
-        outs.append(o.float())
-    assert rel_l2(outs[0], outs[1]) <= 1e-4
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("MI355_ATTN_ASMV", mode)
+            _C.reload_env()
+            o = torch.full((B, S, H, D), float("nan"), dtype=torch.bfloat16, device=device)
+            lse = torch.empty(B, H, S, dtype=torch.float32, device=device)
+            _C.flash_attn_fwd(q, k, vv, o, lse, D ** -0.5, v_is_f16=half_v)
+            torch.cuda.synchronize()
+            outs.append((o, lse))
+    finally:
+        monkeypatch.delenv("MI355_ATTN_ASMV", raising=False)
+        _C.reload_env()
+    assert torch.isfinite(outs[0][0].float()).all()
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_half_output_is_refused_where_it_is_not_built(device):
+    """out_f16 belongs to the plain fp8 GEMMs.  A bf16 problem must be refused on EVERY path,
+    the small-M (<= 16 rows) weight-streaming one included, instead of silently writing bf16."""
+    for M in (4, 64):
+        x = torch.randn(M, 128, device=device).bfloat16()
+        w = torch.randn(32, 128, device=device).bfloat16()
+        out = torch.zeros(M, 32, dtype=torch.float16, device=device)
+        with pytest.raises(RuntimeError, match="half output"):
+            _C.linear_ex(x, w, out, M=M, N=32, K=128, lda=128, ldw=128, ldo=32, out_f16=True)

@@ -17,6 +17,7 @@ def setv(v):
         os.environ.pop(var, None)
     else:
         os.environ[var] = v
+    _C.reload_env()  # the library reads its switches when it is loaded, not per call
 
 
 bad = 0
