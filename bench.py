@@ -176,6 +176,174 @@ def cpu_baseline(seconds_hint: float = 20.0):
     }
 
 
+class PhaseTimer:
+    """Per-phase device time of a step: `with timer(name):` brackets a region with two events
+    on the current stream; `totals()` sums the regions by name after a synchronisation."""
+
+    def __init__(self):
+        self.spans = []
+
+    def __call__(self, name):
+        import contextlib
+
+        import torch
+
+        @contextlib.contextmanager
+        def span():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                yield
+            finally:
+                e1.record()
+                self.spans.append((name, e0, e1))
+        return span()
+
+    def totals(self):
+        import torch
+
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.spans:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        self.spans = []
+        return out
+
+
+def run_c5(args):
+    """BASELINE config 5: one denoise step of the HunyuanVideo DiT (20 double + 40 single
+    blocks, 24 heads of 128) on 720p x 129 frames -- latents [1, 16, 33, 90, 160], patch
+    (1, 2, 2): 118 800 image tokens + 256 text tokens -- with Ulysses sequence parallelism over
+    the N ranks (reference: models/dits/hunyuanvideo.py:49-410, layers/attention/layer.py:38-154,
+    layers/usp.py:49-158).  Each rank holds a full weight replica and the tokens of its frames
+    (the frame count is padded up to a multiple of N with zero frames, as the reference's
+    shard_latents_for_sp does, configs/pipeline_configs/base.py:353-380); every block does one
+    all-to-all of q|k|v (heads out, sequence in), attention of H / N heads over the whole
+    sequence, one all-to-all back and an all-gather of the text heads.  A "step" is the DiT
+    forward on the rank's shard plus the flow-match Euler update of that shard; nothing else
+    is exchanged.  Strong scaling: the same video at every N."""
+    import torch
+    import torch.distributed as dist
+
+    from sglang_diffusion_amd import _C
+    from sglang_diffusion_amd.layers import attention as attn_mod
+    from sglang_diffusion_amd.layers.attention import Mi355AttentionMetadataBuilder
+    from sglang_diffusion_amd.layers.forward_context import set_forward_context
+    from sglang_diffusion_amd.layers.quantization import Fp8Config
+    from sglang_diffusion_amd.models.hunyuanvideo import (HunyuanVideoArchConfig,
+                                                          HunyuanVideoTransformer3DModel,
+                                                          process_weights_after_loading)
+    from sglang_diffusion_amd.runtime.parallel import init_distributed
+    from sglang_diffusion_amd.runtime.synthetic import hashed_tensor, init_synthetic_weights
+
+    backend = os.environ.get("MI355_BENCH_BACKEND", "nccl")
+    rank, world, local = init_distributed(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1
+                                          else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    dev = torch.device("cuda", local % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    nd, ns = args.layers if args.layers else (20, 40)
+    cfg = HunyuanVideoArchConfig(num_layers=nd, num_single_layers=ns, guidance_embeds=True)
+    if cfg.num_attention_heads % world:
+        raise SystemExit(f"{cfg.num_attention_heads} heads do not divide over {world} ranks")
+    qc = None if args.c5_bf16 else Fp8Config(is_checkpoint_fp8_serialized=False,
+                                            activation_scheme="dynamic")
+    group = dist.group.WORLD if world > 1 else None
+    with torch.device(dev):
+        model = HunyuanVideoTransformer3DModel(cfg, quant_config=qc, sp_group=group)
+    init_synthetic_weights(model, seed=0, host_rng=False)   # same seed on every rank: replicas
+    process_weights_after_loading(model)
+    for p in model.parameters():
+        p.requires_grad_(False)
+
+    frames = args.c5_frames
+    padded = -(-frames // world) * world
+    fl = padded // world
+    h, w = args.c5_hw
+    # the video's latents are a function of (frame, position): every rank draws the whole
+    # tensor's values for ITS frames only
+    full = hashed_tensor("c5.latents", (1, 16, padded, h, w), 0, 1.0, dev)
+    if padded > frames:
+        full[:, :, frames:] = 0
+    x = full[:, :, rank * fl:(rank + 1) * fl].contiguous()
+    del full
+    enc = hashed_tensor("c5.text", (1, 1 + 256, cfg.text_embed_dim), 0, 0.1, dev)
+    guid = torch.tensor([6016.0], device=dev).bfloat16()
+    sig = [1.0 - 0.02 * i for i in range(51)]
+    md = Mi355AttentionMetadataBuilder().build(current_timestep=0)
+    timer = PhaseTimer()
+    step_no = [0]
+
+    @torch.no_grad()
+    def one_step():
+        nonlocal x
+        i = step_no[0] % 50
+        t = torch.tensor([sig[i] * 1000.0], device=dev)
+        with set_forward_context(current_timestep=i, attn_metadata=md):
+            v = model(x, enc, t, guid)
+        nxt = torch.empty_like(x)
+        _C.euler_step(nxt, x, v.contiguous(), sig[i], sig[i + 1])
+        x = nxt
+        step_no[0] += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # one more step with the phases bracketed by events (outside the timed region)
+    attn_mod.PHASE_TIMER = timer
+    one_step()
+    phases = timer.totals()
+    attn_mod.PHASE_TIMER = None
+    ph = torch.tensor([elapsed, phases.get("all_to_all", 0.0), phases.get("attention", 0.0),
+                       phases.get("all_gather", 0.0)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+    elapsed, a2a_ms, attn_ms, ag_ms = ph.tolist()
+    assert bool(torch.isfinite(x.float()).all())
+    step_s = elapsed / args.steps
+    S_img, S_txt, D = padded * (h // 2) * (w // 2), 256, cfg.hidden_size
+    S = S_img + S_txt
+    blocks = nd + ns
+    flops_attn = 4.0 * S * S * D * blocks
+    flops_lin = 24.0 * D * D * S * blocks
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ms_per_step_hunyuanvideo_720p_129f_ulysses", "value": step_s * 1e3,
+            "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": step_s * 1e3, "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16" if args.c5_bf16 else "fp8_e4m3 (W8A8 linears) + bf16 (attention)",
+            "data": "synthetic",
+            "config": {"workload": f"HunyuanVideo DiT, latents [1,16,{frames},{h},{w}] "
+                                   f"({frames} -> {padded} frames over {world} ranks), {S_img} image + "
+                                   f"{S_txt} text tokens, {nd}+{ns} blocks [NOT the metric config]",
+                       "parallelism": f"ulysses{world}", "seq_len": S,
+                       "tokens_per_rank": S_img // world, "heads_per_rank": cfg.num_attention_heads // world},
+            "step_tflops_total": (flops_attn + flops_lin) / step_s / 1e12,
+            "phases_ms_per_step": {"all_to_all": a2a_ms, "attention": attn_ms, "all_gather": ag_ms,
+                                   "linears_and_elementwise": max(0.0, step_s * 1e3 - a2a_ms - attn_ms
+                                                                  - ag_ms)},
+            "phases_note": "event-bracketed regions of one extra step after the timed ones, MAX "
+                           "over ranks; linears_and_elementwise = ms_per_step minus the three",
+            "attention_tflops_per_gpu": flops_attn / world / (attn_ms * 1e-3) / 1e12 if attn_ms else None,
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +376,16 @@ def main():
                     help="seconds after which the line is printed without the c4 object")
     ap.add_argument("--c4-steps", type=int, default=None,
                     help="denoise steps per micro-batch of the c4 job (default: --steps)")
+    ap.add_argument("--workload", default="flux", choices=["flux", "c5"],
+                    help="flux: the metric (and its c4 job); c5: one HunyuanVideo 720p x 129-frame "
+                         "denoise step with Ulysses sequence parallelism over the N ranks (NOT the "
+                         "metric; prints its own JSON line with per-phase times)")
+    ap.add_argument("--c5-frames", type=int, default=33,
+                    help="latent frames of the c5 workload (33 = 129 video frames; padded up to a "
+                         "multiple of N as the reference does)")
+    ap.add_argument("--c5-hw", type=int, nargs=2, default=[90, 160],
+                    help="latent height and width of the c5 workload (720p: 90 x 160)")
+    ap.add_argument("--c5-bf16", action="store_true", help="c5 with bf16 linears instead of W8A8")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, rendezvous over gloo on the host, all-reduce the "
                          "rank numbers and print {launch_check, n_gpus, rank_sum}: tests the "
@@ -235,6 +413,9 @@ def main():
             print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(t.item()),
                               "local_rank": local}))
         return
+
+    if args.workload == "c5":
+        return run_c5(args)
 
     from sglang_diffusion_amd.layers.quantization import Fp8Config
     from sglang_diffusion_amd.models.flux import FluxTransformer2DModel, flux_dev_config

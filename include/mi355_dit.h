@@ -51,7 +51,7 @@ const char* mi355_last_error(void);
  * 12: the entry points and fields of measured-slower variants were withdrawn: mi355_linear_args
  *     lost w_shuffled and the seven kn_* fields (out_f16 is now its last field);
  *     mi355_linear_grouped, mi355_shuffle_weight and mi355_shuffled_weight_bytes are gone.
- *     mi355_reload_env was added. */
+ *     mi355_reload_env and mi355_f16_range_snapshot were added. */
 int mi355_abi_version(void);
 
 /* The library reads its few MI355_* environment switches ONCE, when it is loaded (today:
@@ -244,6 +244,14 @@ int mi355_bf16_to_f16(const void* x, void* y, int64_t rows, int64_t cols, int64_
  * bf16 V (f16_begin == f16_end, mi355_flash_attn_fwd): the denoise stage does exactly that. */
 int mi355_f16_range_status(int64_t* overflow_blocks, int64_t* tiny_blocks, int reset,
                            void* stream);
+
+/* The same two counters without a synchronisation: a copy of {overflow_blocks, tiny_blocks} into
+ * host_counts[0..1] (PINNED host memory that the caller keeps alive until the copy has run) is
+ * queued on `stream` behind the work already there, followed by the zeroing when reset != 0.
+ * The caller reads host_counts after an event it records behind this call -- or, when the call
+ * was captured into a HIP graph with the work it guards, after a replay of that graph has
+ * finished.  No counterpart in the reference (see mi355_f16_range_status). */
+int mi355_f16_range_snapshot(int64_t* host_counts, int reset, void* stream);
 
 /* ------------------------------------------------------- norms and rope --
  * rmsnorm(Tensor! output, Tensor input, Tensor weight, float eps, bool pdl)

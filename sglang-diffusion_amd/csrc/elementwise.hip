@@ -1388,6 +1388,22 @@ extern "C" int mi355_f16_range_status(int64_t* overflow_blocks, int64_t* tiny_bl
   return MI355_OK;
 }
 
+extern "C" int mi355_f16_range_snapshot(int64_t* host_counts, int reset, void* stream) {
+  MI355_REQUIRE(host_counts != nullptr, "f16_range_snapshot: null pointer");
+  unsigned long long* counters = mi355_f16_range_counters();
+  if (!counters) return MI355_EHIP;
+  hipStream_t st = (hipStream_t)stream;
+  // queued behind the work already on the stream; nothing here waits for it
+  hipError_t e = hipMemcpyAsync(host_counts, counters, 2 * sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && reset) e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), st);
+  if (e != hipSuccess) {
+    mi355_set_error("f16_range_snapshot: %s", hipGetErrorString(e));
+    return MI355_EHIP;
+  }
+  return MI355_OK;
+}
+
 // ---------------------------------------------------- merge of attention states ----
 // Two partial attention results over disjoint key sets, each normalised by its own softmax
 // sum, and their log-sum-exps -> the result over the union

@@ -7,8 +7,10 @@ shared object is missing every op raises.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -98,6 +100,7 @@ SIGNATURES = {
     "mi355_flash_attn_fwd_f16v": (_int, [_ptr] * 5 + [_i64] * 18 + [_f32, _int, _ptr]),
     "mi355_bf16_to_f16": (_int, [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr]),
     "mi355_f16_range_status": (_int, [ctypes.POINTER(_i64), ctypes.POINTER(_i64), _int, _ptr]),
+    "mi355_f16_range_snapshot": (_int, [_ptr, _int, _ptr]),
     "mi355_rmsnorm": (_int, [_ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _i64, _f32, _ptr]),
     "mi355_fused_add_rmsnorm": (_int, [_ptr, _ptr, _ptr, _int, _i64, _i64, _f32, _ptr]),
     "mi355_qk_norm_rope": (
@@ -423,11 +426,32 @@ def value_to_f16(v: torch.Tensor) -> torch.Tensor:
     return out
 
 
-# Process-wide switch of the V operand's format.  True: V is converted to IEEE half and the
+# Process-wide DEFAULT of the V operand's format.  True: V is converted to IEEE half and the
 # P.V product runs in half (closest to the fp32-softmax result).  False: V stays bf16 and the
 # probabilities are rounded to bf16 (the form every flash kernel the reference calls uses).
-# The denoise stage clears it when a conversion left half's range (f16_range_status).
+# A caller that must deviate for a while (the denoise stage re-running ONE request batch whose
+# values left half's range) does so with `value_half_as`, which ends with its `with` block.
 VALUE_HALF = True
+_value_half_local = threading.local()
+
+
+def value_half() -> bool:
+    """The V format in force on this thread: the innermost `value_half_as`, else VALUE_HALF."""
+    stack = getattr(_value_half_local, "stack", None)
+    return bool(stack[-1]) if stack else bool(VALUE_HALF)
+
+
+@contextlib.contextmanager
+def value_half_as(flag: bool):
+    """Run a block with half (True) or bf16 (False) V, whatever the process default says."""
+    stack = getattr(_value_half_local, "stack", None)
+    if stack is None:
+        stack = _value_half_local.stack = []
+    stack.append(bool(flag))
+    try:
+        yield
+    finally:
+        stack.pop()
 
 
 def f16_range_status(device=None, reset: bool = True):
@@ -450,10 +474,23 @@ def f16_range_reset(device=None) -> None:
             None, None, 1, torch.cuda.current_stream(dev).cuda_stream), "f16_range_status")
 
 
+def f16_range_snapshot(pinned: torch.Tensor, reset: bool = True, device=None) -> None:
+    """Queue a copy of the device's two range counters into `pinned` (int64[2], pinned host
+    memory) on its current stream, then their zeroing; no synchronisation, capturable in a HIP
+    graph.  Read `pinned` after an event recorded behind this call (or after a graph replay)."""
+    if pinned.dtype != torch.int64 or pinned.numel() < 2 or pinned.is_cuda or not pinned.is_pinned():
+        raise RuntimeError("f16_range_snapshot: a pinned host int64[2] tensor is expected")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        _check(load_library().mi355_f16_range_snapshot(
+            pinned.data_ptr(), int(bool(reset)), torch.cuda.current_stream(dev).cuda_stream),
+            "f16_range_snapshot")
+
+
 def attention(q, k, v, out, lse, softmax_scale: float) -> None:
-    """Dense attention on bf16 q, k, v: half-precision P.V product while VALUE_HALF holds,
+    """Dense attention on bf16 q, k, v: half-precision P.V product while value_half() holds,
     else the bf16 form."""
-    if VALUE_HALF:
+    if value_half():
         flash_attn_fwd(q, k, value_to_f16(v), out, lse, softmax_scale, False, v_is_f16=True)
     else:
         flash_attn_fwd(q, k, v, out, lse, softmax_scale, False, v_is_f16=False)

@@ -9,6 +9,7 @@ backend raises.
 """
 from __future__ import annotations
 
+import contextlib
 import enum
 from abc import ABC, abstractmethod
 from dataclasses import dataclass, fields
@@ -334,6 +335,15 @@ class USPAttention(nn.Module):
         return torch.cat([torch.cat(parts, dim=2), out_shard], dim=1)
 
 
+# Optional per-phase timing of the sequence-parallel wrappers (benchmarks only): a callable
+# name -> context manager; None (the default) costs one attribute read per phase.
+PHASE_TIMER = None
+
+
+def _phase(name: str):
+    return PHASE_TIMER(name) if PHASE_TIMER is not None else contextlib.nullcontext()
+
+
 def _append_tokens(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """[B, Sa, H, D] followed by [B, Sb, H, D] along the token dimension.  When `b` already
     sits right behind `a` in one buffer with the same strides (the two streams' slices of a
@@ -391,7 +401,9 @@ class UlyssesAttention(nn.Module):
         if P > 1:
             if H % P:
                 raise ValueError(f"{H} heads do not divide over {P} ranks")
-            qkv = ulysses_all_to_all(torch.cat([q, k, v], dim=0), group, scatter_dim=2, gather_dim=1)
+            with _phase("all_to_all"):
+                qkv = ulysses_all_to_all(torch.cat([q, k, v], dim=0), group, scatter_dim=2,
+                                         gather_dim=1)
             q, k, v = qkv.chunk(3, dim=0)
         n_main = q.shape[1]
         if replicated_q is not None:
@@ -401,7 +413,8 @@ class UlyssesAttention(nn.Module):
             q = _append_tokens(q, replicated_q[:, :, hs])
             k = _append_tokens(k, replicated_k[:, :, hs])
             v = _append_tokens(v, replicated_v[:, :, hs])
-        out = self.attn_impl.forward(q, k, v, md)
+        with _phase("attention"):
+            out = self.attn_impl.forward(q, k, v, md)
         rep_out = None
         if replicated_q is not None:
             rep_out = out[:, n_main:]
@@ -409,7 +422,9 @@ class UlyssesAttention(nn.Module):
             if P > 1:
                 from ..runtime.parallel import all_gather_tensors
 
-                rep_out = torch.cat(all_gather_tensors(rep_out, group), dim=2)
+                with _phase("all_gather"):
+                    rep_out = torch.cat(all_gather_tensors(rep_out, group), dim=2)
         if P > 1:
-            out = ulysses_all_to_all(out.contiguous(), group, scatter_dim=1, gather_dim=2)
+            with _phase("all_to_all"):
+                out = ulysses_all_to_all(out.contiguous(), group, scatter_dim=1, gather_dim=2)
         return out, rep_out

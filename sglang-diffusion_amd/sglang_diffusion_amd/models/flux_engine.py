@@ -315,8 +315,8 @@ class FluxEngine:
         scale = dh ** -0.5
         # the V third of every fused q|k|v projection is written in half format: the attention
         # kernel multiplies half probabilities with half values (bf16 V and bf16 probabilities
-        # once a value left half's range, see _C.VALUE_HALF)
-        v_half = bool(_C.VALUE_HALF)
+        # where a caller asked for it, see _C.value_half)
+        v_half = _C.value_half()
         vcols = (2 * D, 3 * D) if v_half else None
         if self.block:
             def quant(x, q, s_):  # per (token, 128 channels), fp8.py:303-352 on a block checkpoint

@@ -50,13 +50,22 @@ class Req:
 
 class DenoisingStage:
     def __init__(self, transformer, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None,
-                 fused: bool = True, cfg_batched: bool = True, cfg_group=None):
+                 fused: bool = True, cfg_batched: bool = True, cfg_group=None, sync_group=None,
+                 value_half: Optional[bool] = None, half_fallback_limit: int = 2):
         """cfg_group: a 2-rank process group over which the conditional (rank 0) and the
         unconditional (rank 1) branch of true CFG are split (the reference's
         enable_cfg_parallel, pipelines_core/stages/denoising.py:1388-1446); None = both
-        branches on this rank."""
+        branches on this rank.  sync_group: any further group whose ranks run collectives with
+        this one inside a step and therefore must take the half / bf16 V decision together.
+        value_half: None follows the process default (_C.VALUE_HALF), False pins bf16 V."""
         self.transformer = transformer
         self.cfg_group = cfg_group
+        self.sync_group = sync_group
+        self.value_half = value_half
+        self.half_fallback_limit = max(1, int(half_fallback_limit))
+        self._half_failures = 0
+        self._range_host = {}    # device -> pinned int64[2]
+        self._range_event = {}   # device -> event behind the last snapshot
         # Flux ships use_dynamic_shifting=True in its scheduler config
         self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler(use_dynamic_shifting=True)
         self.fused = fused
@@ -190,32 +199,103 @@ class DenoisingStage:
         if batch.guidance_rescale > 0.0:
             _C.guidance_rescale(noise_pred, cond, float(batch.guidance_rescale), scratch)
 
+    # ---- the half-format V operand and its range guard -------------------------------------
+    def _range_buffer(self, device) -> torch.Tensor:
+        """Pinned host int64[2] that receives {overflow_blocks, tiny_blocks} of this stage's last
+        request batch on `device`."""
+        key = str(device)
+        if key not in self._range_host:
+            self._range_host[key] = torch.zeros(2, dtype=torch.int64).pin_memory()
+        return self._range_host[key]
+
+    def range_counts(self, device=None, wait: bool = True):
+        """(overflow_blocks, tiny_blocks) of the bf16 -> half conversions of the last request batch
+        this stage ran on `device`.  `forward` queues their copy to pinned host memory behind the
+        batch; this call waits for that copy (an event, not a device synchronisation) and reads
+        it.  A caller that captured `forward` into a HIP graph calls it after a replay has
+        finished: non-zero counts mean that replay's latents must be discarded and the batch
+        redone with bf16 V (`value_half=False`)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        ev = self._range_event.get(str(dev))
+        if ev is not None and wait:
+            ev.synchronize()
+        elif wait:
+            torch.cuda.current_stream(dev).synchronize()   # captured batch: no event exists
+        host = self._range_buffer(dev)
+        return int(host[0]), int(host[1])
+
+    def _agree(self, over: int, tiny: int, device):
+        """Every rank that shares collectives with this one inside a step (the CFG pair, a
+        sequence-parallel group) must take the same branch after the loop: the largest count
+        of the group decides for all of it."""
+        import torch.distributed as dist
+
+        from .parallel import _wire
+
+        for group in self._decision_groups():
+            t = torch.tensor([over, tiny], dtype=torch.int64, device=device)
+            w = _wire(t, group)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
+            over, tiny = int(w[0]), int(w[1])
+        return over, tiny
+
+    def _decision_groups(self):
+        groups = [g for g in (self.cfg_group, self.sync_group) if g is not None]
+        sp = getattr(self.transformer, "sp_group", None)
+        if sp is not None:
+            groups.append(sp)
+        return groups
+
     @torch.no_grad()
     def forward(self, batch: Req, num_steps: Optional[int] = None) -> Req:
         """Runs the loop in place on `batch.latents`; `num_steps` truncates it (benchmarks).
 
         The attention kernels take V in IEEE half (exact for 2^-14 <= |v| <= 65504).  Every
-        conversion is range-checked on the device; the counters are read once here, after the
-        loop, and if a value left the range the whole loop is run again from the initial
-        latents with bf16 V (and stays that way for the process): wrong values never leave
-        this call, and the common case pays one 16-byte copy per request batch."""
-        first = batch.latents
-        check = _C.VALUE_HALF and first.is_cuda and not torch.cuda.is_current_stream_capturing()
-        if check:
-            _C.f16_range_reset(first.device)   # counts of earlier, unrelated work do not matter
-        out = self._loop(batch, num_steps)
-        if check:
-            over, tiny = _C.f16_range_status(first.device, reset=True)
-            if over or tiny:
-                import warnings
+        conversion is range-checked on the device.  The two counters are zeroed before the loop
+        and copied to pinned host memory behind it, both on the launch stream and without a
+        synchronisation; the stage then waits for that copy (an event) and, if a value left the
+        range in THIS batch, runs THIS batch again from its initial latents with bf16 V.  The
+        process default and other stages are not touched; a stage whose batches keep failing
+        (`half_fallback_limit` in a row) stops trying half for itself.  Ranks that share
+        collectives inside a step agree on the decision first (`_agree`).
 
-                warnings.warn(f"attention V left IEEE half's range in this request batch ({over} "
-                              f"blocks beyond 65504, {tiny} blocks entirely below 2^-13): "
-                              "re-running it with bf16 V, which stays on for this process")
-                _C.VALUE_HALF = False
-                batch.latents = first
-                out = self._loop(batch, num_steps)
-        return out
+        Under HIP graph capture nothing can be read back: the zeroing, the loop and the copy are
+        captured, and the caller polls `range_counts()` after each replay."""
+        first = batch.latents
+        use_half = (self.value_half if self.value_half is not None else _C.value_half()) \
+            and first.is_cuda
+        if not use_half:
+            with _C.value_half_as(False):
+                return self._loop(batch, num_steps)
+        dev = first.device
+        capturing = torch.cuda.is_current_stream_capturing()
+        host = self._range_buffer(dev)
+        _C.f16_range_reset(dev)        # counts of earlier, unrelated work do not matter
+        with _C.value_half_as(True):
+            out = self._loop(batch, num_steps)
+        _C.f16_range_snapshot(host, reset=True, device=dev)
+        if capturing:
+            self._range_event.pop(str(dev), None)
+            return out
+        ev = self._range_event[str(dev)] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        over, tiny = self._agree(*self.range_counts(dev), dev)
+        if not (over or tiny):
+            self._half_failures = 0
+            return out
+        import warnings
+
+        self._half_failures += 1
+        giving_up = self._half_failures >= self.half_fallback_limit
+        warnings.warn(f"attention V left IEEE half's range in this request batch ({over} blocks "
+                      f"beyond 65504, {tiny} blocks entirely below 2^-13): re-running the batch "
+                      "with bf16 V" + (f"; {self._half_failures} batches in a row did, this stage "
+                                       "keeps bf16 V from now on" if giving_up else ""))
+        if giving_up:
+            self.value_half = False
+        batch.latents = first
+        with _C.value_half_as(False):
+            return self._loop(batch, num_steps)
 
     def _loop(self, batch: Req, num_steps: Optional[int] = None) -> Req:
         device = batch.latents.device

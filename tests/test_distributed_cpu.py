@@ -356,3 +356,89 @@ def _cfg_parallel_stage_case(rank):
 def test_cfg_parallel_stage_with_post_combine_steps():
     ret = _run(_cfg_parallel_stage_case)
     assert ret[0] == (True, True) and ret[1] == (True, True)
+
+
+# ------------------------------------------------------------ scheduling under load --------
+class _SleepStage:
+    """Stand-in denoiser: 0.25 s per DiT sample, final latents = 2 * latents + 1."""
+
+    transformer = None
+
+    def forward(self, batch, num_steps=None):
+        import time
+
+        from sglang_diffusion_amd.runtime.batch_scheduler import request_cost
+
+        time.sleep(0.25 * request_cost(batch))
+        batch.latents = batch.latents * 2 + 1
+        return batch
+
+
+def _tiny_request(batch, fill):
+    from sglang_diffusion_amd.runtime.denoise import Req
+
+    return Req(latents=torch.full((batch, 4, 8), float(fill)), prompt_embeds=torch.zeros(batch, 2, 8),
+               pooled_embeds=torch.zeros(batch, 8), height=64, width=64, num_inference_steps=2)
+
+
+def _async_case(rank):
+    """Staggered arrivals on two ranks.  Rank 0 gets a long request (4 samples = 1 s) and
+    computes it; meanwhile a submitter thread keeps admitting short ones, which all go to rank
+    1 (least outstanding cost) WHILE it computes, are micro-batched there, and come back to
+    rank 0 one by one before rank 0's own long request is done."""
+    import threading
+    import time
+
+    from sglang_diffusion_amd.runtime.async_scheduler import AsyncDataParallelScheduler
+
+    sch = AsyncDataParallelScheduler(_SleepStage(), rank, WORLD, max_samples_per_step=4)
+    sch.start()
+    if rank != 0:
+        n = sch.serve()
+        return {"microbatches": n, "log": [(w, i) for w, i, _ in sch.log],
+                "times": {(w, i): t for w, i, t in sch.log}}
+    t0 = time.perf_counter()
+
+    def arrivals():
+        sch.submit(_tiny_request(4, 10), "long")          # -> rank 0 (both idle, lower rank)
+        sch.submit(_tiny_request(1, 1), "a")               # -> rank 1
+        time.sleep(0.1)
+        sch.submit(_tiny_request(1, 2), "b")               # rank 1 is computing "a": admitted anyway
+        time.sleep(0.05)
+        sch.submit(_tiny_request(1, 3), "c")
+        time.sleep(0.5)
+        sch.submit(_tiny_request(1, 4), "d")               # after "a" returned: still rank 1
+
+    th = threading.Thread(target=arrivals)
+    th.start()
+    time.sleep(0.02)                                       # let the first submissions land
+    sch.serve_local()
+    th.join()
+    while sch.pending():
+        sch.serve_local()
+    got = dict(sch.results())
+    sch.shutdown()
+    times = {(w, i): t - t0 for w, i, t in sch.log}
+    return {"values": {k: v.flatten()[0].item() for k, v in got.items()},
+            "shapes": {k: tuple(v.shape) for k, v in got.items()}, "times": times,
+            "order": [i for w, i, _ in sch.log if w == "returned"]}
+
+
+def test_async_scheduler_admits_while_computing_and_returns_per_request():
+    ret = _run(_async_case)
+    r0, r1 = ret[0], ret[1]
+    # every request came back with the right latents
+    assert r0["values"] == {"long": 21.0, "a": 3.0, "b": 5.0, "c": 7.0, "d": 9.0}
+    assert r0["shapes"]["long"] == (4, 4, 8) and r0["shapes"]["a"] == (1, 4, 8)
+    # per-request return: rank 1's short requests are back before rank 0's long one is done
+    order = r0["order"]
+    assert order.index("a") < order.index("long") and order.index("b") < order.index("long")
+    assert r0["times"][("returned", "a")] < r0["times"][("returned", "long")] - 0.3
+    # admission while computing: "b" and "c" reached rank 1 while "a" was still running there
+    # (0.25 s), and were then run together as ONE micro-batch
+    log1 = r1["log"]
+    assert log1.index(("admitted", "b")) < log1.index(("started", "b"))
+    t1 = r1["times"]
+    assert t1[("admitted", "b")] < t1[("started", "a")] + 0.25
+    assert abs(t1[("started", "b")] - t1[("started", "c")]) < 0.05
+    assert r1["microbatches"] == 3                          # a | b + c | d

@@ -40,7 +40,7 @@ S = TT + TI
 #   W8A8 <= 3e-3 / 2e-3: the input of every quantised linear is re-rounded to e4m3 (3 mantissa
 #     bits); a one-ulp bf16 difference upstream moves an fp8 code now and then and costs 2^-4
 #     relative on that element (qkv GEMM alone: 2.5e-4 against 4e-5 in bf16).
-BAR = {("d", False): 2e-3, ("s", False): 1e-3, ("d", True): 3e-3, ("s", True): 2e-3}
+from tests.real_width_bars import BAR  # noqa: E402  (shared with the CPU floor measurement)
 
 
 def _real_width(device, fp8):

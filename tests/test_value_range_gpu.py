@@ -146,14 +146,81 @@ def test_denoise_stage_falls_back_to_bf16_v_on_its_own(device):
     for name in ("latents", "prompt_embeds", "pooled_embeds"):
         setattr(req, name, getattr(req, name).to(device))
     assert _C.VALUE_HALF
-    try:
-        with warnings.catch_warnings(record=True) as caught:
-            warnings.simplefilter("always")
-            out = DenoisingStage(model, fused=True).forward(req).latents
-        assert any("half's range" in str(w.message) for w in caught)
-        assert _C.VALUE_HALF is False                      # sticky for the process
-        e = rel_l2(out, ref)
-        print(f"denoise with an overflowing value projection, after the fallback: rel {e:.2e}")
-        assert e <= 8e-3
-    finally:
-        _C.VALUE_HALF = True
+    stage = DenoisingStage(model, fused=True)
+    first = {k_: getattr(req, k_).clone() for k_ in ("latents",)}
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out = stage.forward(req).latents
+    assert any("half's range" in str(w.message) for w in caught)
+    over, tiny = stage.range_counts()
+    assert over > 0
+    # the fallback belongs to THIS batch of THIS stage: the process default is untouched, and
+    # the stage itself tries half again on its next batch
+    assert _C.VALUE_HALF is True and _C.value_half() is True and stage.value_half is None
+    e = rel_l2(out, ref)
+    print(f"denoise with an overflowing value projection, after the fallback: rel {e:.2e}")
+    assert e <= 8e-3
+    # a second failing batch in a row: the stage (not the process) gives half up for itself
+    req.latents = first["latents"]
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out2 = stage.forward(req).latents
+    assert any("keeps bf16 V" in str(w.message) for w in caught)
+    assert stage.value_half is False and _C.VALUE_HALF is True
+    assert torch.equal(out2, out)
+    req.latents = first["latents"]
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out3 = stage.forward(req).latents              # bf16 V from the start: no warning, same bits
+    assert not any("half's range" in str(w.message) for w in caught)
+    assert torch.equal(out3, out)
+
+
+def test_range_counts_after_a_graph_replay(device):
+    """A caller that replays a captured request batch cannot have the stage read counters in
+    the middle: the zeroing, the loop and the copy of the counters to pinned host memory are
+    captured with the batch, and `range_counts()` after a replay tells whether that replay's V
+    left half's range.  One model that does (to_v scaled by 1e5), one that does not."""
+    from sglang_diffusion_amd import _C
+    from sglang_diffusion_amd.models.flux import FluxArchConfig, FluxTransformer2DModel
+    from sglang_diffusion_amd.runtime.denoise import DenoisingStage
+    from sglang_diffusion_amd.runtime.synthetic import init_synthetic_weights, make_synthetic_request
+    from tests.flux_small import SMALL
+
+    cfg = FluxArchConfig(**SMALL, guidance_embeds=True)
+    for scale_v, expect_over in ((1.0, False), (1e5, True)):
+        model = FluxTransformer2DModel(cfg, quant_config=None)
+        init_synthetic_weights(model, seed=0, host_rng=True)
+        with torch.no_grad():
+            a = model.transformer_blocks[0].attn
+            a.to_v.weight.mul_(scale_v)
+            a.to_v.bias.mul_(scale_v)
+            a.to_out[0].weight.mul_(1.0 / scale_v)
+        model = model.to(device)
+        model.process_weights_after_loading()
+        stage = DenoisingStage(model, fused=True)
+        req = make_synthetic_request(2, height=96, width=128, num_inference_steps=2, device=device,
+                                     seed=3, text_len=24, joint_dim=cfg.joint_attention_dim,
+                                     pooled_dim=cfg.pooled_projection_dim)
+        static_lat = req.latents.clone()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            eager = stage.forward(req, num_steps=1).latents.clone()   # warm-up: workspaces exist
+        stage.value_half, stage._half_failures = None, 0
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        req.latents = static_lat
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                captured = stage.forward(req, num_steps=1).latents
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(2):
+            _C.f16_range_reset(device)
+            graph.replay()
+            torch.cuda.synchronize()
+            over, tiny = stage.range_counts(wait=False)
+            print(f"to_v x {scale_v:g}: counters after a replay: overflow {over}, tiny {tiny}")
+            assert (over > 0) == expect_over
+        if not expect_over:
+            assert torch.equal(captured, eager)          # the replay IS the eager batch

@@ -33,6 +33,58 @@ def dense(q, k, v):
     return out
 
 
+def half_v_guard_with_cfg_parallel(rank, dev, group):
+    """The denoise stage with the two CFG branches on the two ranks (an all-reduce and, with
+    guidance rescale, a broadcast in EVERY step) when only ONE rank's half-format V leaves
+    half's range: both ranks must re-run the batch with bf16 V together -- a rank that went on
+    alone would sit in a collective its peer never joins.  The overflow is a real one, counted
+    by the device counters: rank 1 converts a tensor holding 1e6 to half right behind its
+    first pass over the batch."""
+    import warnings
+
+    from sglang_diffusion_amd.models.flux import FluxArchConfig, FluxTransformer2DModel
+    from sglang_diffusion_amd.runtime.denoise import DenoisingStage
+    from sglang_diffusion_amd.runtime.synthetic import init_synthetic_weights, make_synthetic_request
+    from tests.flux_small import SMALL
+
+    cfg = FluxArchConfig(**SMALL, guidance_embeds=True)
+    model = FluxTransformer2DModel(cfg, quant_config=None)
+    init_synthetic_weights(model, seed=0, host_rng=True)
+    model = model.to(dev)
+    model.process_weights_after_loading()
+
+    def request():
+        return make_synthetic_request(2, height=96, width=128, num_inference_steps=2, device=dev,
+                                      seed=3, text_len=24, joint_dim=cfg.joint_attention_dim,
+                                      pooled_dim=cfg.pooled_projection_dim, true_cfg=True,
+                                      guidance_scale=3.5)
+
+    # what the pair computes with bf16 V from the start
+    want = DenoisingStage(model, fused=True, cfg_group=group, value_half=False).forward(request()).latents
+    stage = DenoisingStage(model, fused=True, cfg_group=group)
+    passes = []
+    inner = stage._loop
+
+    def loop(batch, num_steps=None):
+        out = inner(batch, num_steps)
+        passes.append(_C.value_half())
+        if rank == 1 and len(passes) == 1:
+            big = torch.full((8, 128), 1e6, dtype=torch.bfloat16, device=dev)
+            _C.bf16_to_f16(big, torch.empty_like(big))
+        return out
+
+    stage._loop = loop
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = stage.forward(request()).latents
+    torch.cuda.synchronize()
+    warned = any("half's range" in str(w.message) for w in caught)
+    ok = passes == [True, False] and warned and bool(torch.equal(got, want))
+    flag = torch.tensor([int(ok)])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return {"half_v_guard_ranks_decide_together_exact": bool(flag.item())}
+
+
 def main():
     rank, world, _ = init_distributed("gloo")
     assert world == 2
@@ -96,6 +148,7 @@ def main():
         mine = (cond if rank == 0 else uncond).to(dev)
         comb = cfg_parallel_combine(mine, 3.5, g)
         res["cfg_parallel_exact"] = bool(torch.equal(comb.cpu(), 3.5 * cond + (1 - 3.5) * uncond))
+    res.update(half_v_guard_with_cfg_parallel(rank, dev, g))
     torch.cuda.synchronize()
     dist.barrier()
     flags = torch.tensor([int(all(v for k, v in res.items() if k.endswith("exact")))])
