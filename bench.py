@@ -470,6 +470,7 @@ def main():
     model._engine = model._engine or FluxEngine(model)
     if args.no_overlap_text:
         model._engine.overlap_text = False
+        model._engine.overlap_mlp = False
     B = args.batch
     req = make_synthetic_request(B, 1024, 1024, NUM_INFERENCE_STEPS, device=dev, seed=rank)
     timesteps = stage.prepare_timesteps(req, dev)

@@ -185,6 +185,9 @@ class FluxEngine:
         # and probes fall back to one stream, where a launch's events mean something.
         # MI355_FLUX_OVERLAP_TEXT=0 turns it off.
         self.overlap_text = os.environ.get("MI355_FLUX_OVERLAP_TEXT", "1") == "1"
+        # single blocks: proj_mlp beside the attention branch on the second stream
+        # (MI355_FLUX_OVERLAP_MLP=0 turns it off)
+        self.overlap_mlp = os.environ.get("MI355_FLUX_OVERLAP_MLP", "1") == "1"
         self._side_streams: Dict[str, torch.cuda.Stream] = {}
 
     def _side(self, dev) -> torch.cuda.Stream:
@@ -413,19 +416,31 @@ class FluxEngine:
         # ------------------------------------------------------------------ single blocks --
         cat = ws["cat"]
         catw = cat.shape[1]
+        side_single = (self._side(dev) if (self.overlap_mlp and self.trace is None
+                                           and probe is None) else None)
         attn_in_cat = cat.view(B, S, catw)[:, :, :D].unflatten(-1, (H, dh))
         mlp_cols = cat[:, D:]
         for i, blk in enumerate(self.sgl):
             tell("before", "s", i)
             off = self.mod_off[("s", i)]
             a, sa = norm_in(blk["qkv"].fp8, chunk(off, 0), chunk(off, 1), S, None, Ms)
+            # proj_mlp (+ GELU) does not depend on the attention branch: on the second stream
+            # its tiles fill the CUs that the q|k|v projection's and the attention's partial
+            # last rounds leave idle (same bits; joined before the concatenation is quantised)
+            if side_single is not None:
+                side_single.wait_event(main.record_event())
+                with torch.cuda.stream(side_single):
+                    self._lin(blk["mlp"], a, mlp_cols, M=Ms, sa=sa, act=1, ldo=catw)
             self._lin(blk["qkv"], a, qkv, M=Ms, sa=sa, f16_cols=vcols)
-            self._lin(blk["mlp"], a, mlp_cols, M=Ms, sa=sa, act=1, ldo=catw)
+            if side_single is None:
+                self._lin(blk["mlp"], a, mlp_cols, M=Ms, sa=sa, act=1, ldo=catw)
             self._run("elementwise", 0.0, 4.0 * Ms * D, _C.qk_norm_rope, None, k, blk["nq"],
                       blk["nk"], blk["nq"], blk["nk"], 0, blk["eps"], cos, sin, True)
             self._run("attention", 4.0 * B * S * S * D, 8.0 * Ms * D, _C.flash_attn_fwd, q, k, v,
                       attn_in_cat, None, scale, False, v_half,
                       q_norm=(blk["nq"], blk["nq"], 0, blk["eps"]), q_rope=(cos, sin))
+            if side_single is not None:
+                main.wait_event(side_single.record_event())
             if blk["out"].fp8:
                 self._run("elementwise", 0.0, 3.0 * Ms * catw, quant, cat, ws["cq"], ws["cs"])
                 c_src, c_s = ws["cq"], ws["cs"]

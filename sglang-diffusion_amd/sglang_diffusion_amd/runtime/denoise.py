@@ -72,6 +72,7 @@ class DenoisingStage:
         self.cfg_batched = cfg_batched
         self.attn_metadata_builder = Mi355AttentionMetadataBuilder()
         self._freqs = {}
+        self._ts_dev = {}  # (steps, height, width, device) -> (device timesteps, host copy)
         self._bufs = {}  # per-shape scratch and staging tensors: a step allocates nothing
 
     def _buf(self, name: str, shape, dtype, device) -> torch.Tensor:
@@ -108,8 +109,22 @@ class DenoisingStage:
         mu from the image size."""
         sigmas = prepare_sigmas(batch.num_inference_steps)
         mu = prepare_mu(batch.height, batch.width, pc.VAE_SCALE_FACTOR)
-        self.scheduler.set_timesteps(sigmas=list(sigmas), mu=mu, device=device)
-        return self.scheduler.timesteps
+        # the schedule is built on the host; its device copy is kept per (steps, size, device),
+        # so a batch that is being captured into a HIP graph (where a host-to-device copy from
+        # pageable memory is not allowed) finds the copy its warm-up run left behind
+        self.scheduler.set_timesteps(sigmas=list(sigmas), mu=mu, device=None)
+        if torch.device(device).type == "cpu":
+            return self.scheduler.timesteps
+        key = (batch.num_inference_steps, batch.height, batch.width, str(device))
+        ts = self._ts_dev.get(key)
+        if ts is None or not torch.equal(ts[1], self.scheduler.timesteps):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("DenoisingStage: run a batch of this shape once outside the "
+                                   "graph capture first (its timestep table has to be on the device)")
+            ts = self._ts_dev[key] = (self.scheduler.timesteps.to(device),
+                                      self.scheduler.timesteps.clone())
+        self.scheduler.timesteps = ts[0]
+        return ts[0]
 
     def _dit(self, **kw):
         return self.transformer.forward_fused(**kw) if self.fused else self.transformer(**kw)

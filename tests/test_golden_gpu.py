@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from sglang_diffusion_amd import _C
-from tests.helpers import bf16, bf16_ulp_diff, fp8, load_golden, rel_l2
+from tests.helpers import assert_close_bf16, bf16, bf16_ulp_diff, fp8, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -84,7 +84,10 @@ def test_gelu_tanh_vs_reference_gelu_tanh_and_mul_cpu(device):
     _C.activation(out, x, 1)
     torch.cuda.synchronize()
     _close(out, bf16(z["out"]))
-    assert bf16_ulp_diff(out, bf16(z["out"])).max() <= 1
+    # one bf16 ulp, judged on the scale of the operands: for x << 0 the sum 1 + tanh(u) cancels
+    # and the two implementations of tanh leave different dust (-0.0 here, -1e-8 there), which
+    # an ulp count of the RESULT would call thousands of ulps
+    assert_close_bf16(out, bf16(z["out"]), rel=1e-3, max_ulps=1.0, what="gelu_tanh")
 
 
 def test_block_fp8_weight_gemm_vs_reference_fp8_scaled_mm_cpu(device):
