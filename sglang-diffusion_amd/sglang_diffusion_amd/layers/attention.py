@@ -150,7 +150,10 @@ class Mi355AttentionImpl(AttentionImpl):
         self.causal = causal
 
     def forward(self, query, key, value, attn_metadata=None, *, return_softmax_lse: bool = False,
-                out: Optional[torch.Tensor] = None):
+                out: Optional[torch.Tensor] = None, value_is_half: bool = False):
+        """value_is_half: the 16-bit words of `value` already hold IEEE half (the producing
+        GEMM wrote them that way, mi355_linear_args.f16_begin / f16_end): the conversion pass
+        of the default path is skipped, the arithmetic is the same."""
         if query.dtype != torch.bfloat16:
             raise TypeError(f"attention expects bf16, got {query.dtype}")
         B, S, H, D = query.shape
@@ -158,7 +161,10 @@ class Mi355AttentionImpl(AttentionImpl):
             out = torch.empty((B, S, H, D), dtype=query.dtype, device=query.device)
         lse = (torch.empty((B, H, S), dtype=torch.float32, device=query.device)
                if return_softmax_lse else None)
-        _C.attention(query, key, value, out, lse, self.softmax_scale)
+        if value_is_half:
+            _C.flash_attn_fwd(query, key, value, out, lse, self.softmax_scale, False, v_is_f16=True)
+        else:
+            _C.attention(query, key, value, out, lse, self.softmax_scale)
         return (out, lse) if return_softmax_lse else out
 
 
@@ -387,7 +393,11 @@ class UlyssesAttention(nn.Module):
         self.num_heads, self.head_size, self.num_kv_heads = num_heads, head_size, num_kv_heads
         self.group = group
 
-    def forward(self, q, k, v, replicated_q=None, replicated_k=None, replicated_v=None):
+    def forward(self, q, k, v, replicated_q=None, replicated_k=None, replicated_v=None, *,
+                value_is_half: bool = False, out: Optional[torch.Tensor] = None):
+        """value_is_half: see Mi355AttentionImpl.forward.  out: with ONE rank, a [B, S + S_rep, H,
+        D] buffer (any row stride) the kernel writes the joint result into -- the two returned
+        tensors are then views of it; ignored when the result comes out of an exchange."""
         assert q.dim() == 4 and k.dim() == 4 and v.dim() == 4, "Expected 4D tensors"
         import torch.distributed as dist
 
@@ -413,8 +423,11 @@ class UlyssesAttention(nn.Module):
             q = _append_tokens(q, replicated_q[:, :, hs])
             k = _append_tokens(k, replicated_k[:, :, hs])
             v = _append_tokens(v, replicated_v[:, :, hs])
+        kw = {"value_is_half": True} if value_is_half else {}
+        if out is not None and P == 1 and tuple(out.shape) == tuple(q.shape):
+            kw["out"] = out
         with _phase("attention"):
-            out = self.attn_impl.forward(q, k, v, md)
+            out = self.attn_impl.forward(q, k, v, md, **kw)
         rep_out = None
         if replicated_q is not None:
             rep_out = out[:, n_main:]

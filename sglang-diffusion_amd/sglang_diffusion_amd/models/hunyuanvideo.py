@@ -20,8 +20,17 @@ mi355_gate_residual, mi355_qk_norm_rope) plus the one-pass
 mi355_scale_residual_layernorm_modulate, behind layer classes of the reference's names
 (layers/layernorm.py, layers/elementwise.py here), with two differences in layout: the joint sequence is [video | text] (Flux: [text | image]) and the text
 tokens are not rotated -- the rotation table carries cos = 1, sin = 0 on their rows, which is
-the identity bit for bit.  No fused multi-block schedule exists for this model yet; the blocks
-run layer by layer.
+the identity bit for bit.
+
+Two schedules run the same arithmetic to the same bits.  The LAYER path goes module by module
+through the plugin interfaces (LinearMethodBase.apply, the fused norm layers, MulAdd).  The
+FUSED path (`fused = True`, the default where every linear of the block is bf16 or per-channel
+dynamic fp8) drives the same kernels the way the Flux engine does: the two streams' q|k|v
+projections write into ONE joint buffer through row maps (no torch.cat), V comes out of the
+projection in half format (no conversion pass), tanh-GELU sits in the epilogue of the GEMM that
+feeds it (fc_in, the MLP columns of linear1), the gated residual in the epilogue of fc_out /
+linear2 (no MulAdd pass), LayerNorm + modulation + per-token fp8 quantisation is one pass, and on
+one rank the attention kernel writes straight into linear2's input (no assembly copies).
 """
 from __future__ import annotations
 
@@ -36,8 +45,10 @@ from ..layers.attention import LocalAttention, UlyssesAttention
 from ..layers.elementwise import MulAdd
 from ..layers.layernorm import (LayerNormScaleShift, RMSNorm, ScaleResidualLayerNormScaleShift,
                                 _silu)
+from ..layers.layernorm import _rows_per_sample
 from ..layers.linear import ColumnParallelLinear, ReplicatedLinear
-from ..layers.quantization import QuantizationConfig
+from ..layers.quantization import (FP8_DTYPE, Fp8LinearMethod, QuantizationConfig,
+                                   UnquantizedLinearMethod)
 from ..layers.rotary import NDRotaryEmbedding
 
 
@@ -90,6 +101,57 @@ class MLP(nn.Module):
         return y
 
 
+# ---- helpers of the fused schedule ------------------------------------------------------------
+def _lin_kind(lin) -> Optional[str]:
+    """"bf16", "fp8" (per-channel weights, dynamic per-token activations) or None (a form the
+    fused schedule does not cover: block-quantised or statically scaled layers)."""
+    qm = lin.quant_method
+    if isinstance(qm, UnquantizedLinearMethod):
+        return "bf16"
+    if isinstance(qm, Fp8LinearMethod) and not qm.block_quant \
+            and getattr(lin, "input_scale", None) is None and lin.weight.dtype == FP8_DTYPE:
+        return "fp8"
+    return None
+
+
+def _norm_in(x2: torch.Tensor, shift, scale, B: int, T: int, fp8: bool):
+    """LayerNormScaleShift of [B*T, D] rows (+ per-token fp8 quantisation) in one pass:
+    (activation, per-token scales or None)."""
+    M, D = x2.shape
+    if fp8:
+        a = torch.empty((M, D), dtype=FP8_DTYPE, device=x2.device)
+        sa = torch.empty((M,), dtype=torch.float32, device=x2.device)
+        _C.layernorm_modulate_quant(a, sa, x2, shift, scale, B, T, 1e-6)
+        return a, sa
+    a = torch.empty_like(x2)
+    _C.layernorm_modulate(a, x2, shift, scale, B, T, 1e-6)
+    return a, None
+
+
+def _quant_in(x2: torch.Tensor, fp8: bool):
+    if not fp8:
+        return x2, None
+    q = torch.empty(x2.shape, dtype=FP8_DTYPE, device=x2.device)
+    s = torch.empty((x2.shape[0],), dtype=torch.float32, device=x2.device)
+    _C.per_token_quant_fp8(x2, q, s)
+    return q, s
+
+
+def _gemm(lin, a: torch.Tensor, out: torch.Tensor, *, sa=None, n0: int = 0, n1: Optional[int] = None,
+          act: int = 0, gate=None, residual=None, gate_rows: int = 0, o_map=None, f16_cols=None):
+    """Output channels [n0, n1) of `lin` on the rows of `a` into `out` (its row stride is the
+    leading dimension), with the epilogues of mi355_linear_ex."""
+    w = lin.weight.data
+    n1 = w.shape[0] if n1 is None else n1
+    fp8 = w.dtype == FP8_DTYPE
+    _C.linear_ex(a, w[n0:n1], out, M=a.shape[0], N=n1 - n0, K=w.shape[1], lda=a.stride(0),
+                 ldw=w.stride(0), ldo=out.stride(0), sa=sa,
+                 sb=lin.weight_scale.data[n0:n1] if fp8 else None,
+                 bias=lin.bias.data[n0:n1] if lin.bias is not None else None, residual=residual,
+                 gate=gate, ldg=gate.stride(0) if gate is not None else 0, gate_rows=gate_rows,
+                 o_map=o_map, fp8=fp8, act=act, f16_cols=f16_cols)
+
+
 def _joint_rope_table(cos: torch.Tensor, sin: torch.Tensor, n_text: int
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Rotation table for the joint [video | text] sequence: the text rows rotate by zero."""
@@ -132,6 +194,62 @@ class MMDoubleStreamBlock(nn.Module):
         self.attn = UlyssesAttention(num_heads=num_attention_heads, head_size=head_dim, causal=False,
                                      supported_attention_backends=supported_attention_backends,
                                      prefix=f"{prefix}.attn", group=sp_group)
+        self.fused = True   # False: the layer path (same bits)
+
+    def _fused_kind(self) -> Optional[str]:
+        kinds = {_lin_kind(l) for s in ("img", "txt") for l in (
+            getattr(self, f"{s}_attn_qkv"), getattr(self, f"{s}_attn_proj"),
+            getattr(self, f"{s}_mlp").fc_in, getattr(self, f"{s}_mlp").fc_out)}
+        return kinds.pop() if len(kinds) == 1 else None
+
+    def _forward_fused(self, img, txt, vec, freqs_cis, kind: str):
+        fp8 = kind == "fp8"
+        B, Ti, D = img.shape
+        Tt = txt.shape[1]
+        S, H = Ti + Tt, self.num_attention_heads
+        mods = {"img": torch.chunk(self.img_mod(vec), 6, dim=-1),
+                "txt": torch.chunk(self.txt_mod(vec), 6, dim=-1)}
+        mods = {s: [_rows_per_sample(m, B, D, "modulation") for m in ms] for s, ms in mods.items()}
+        xs = {"img": img.reshape(B * Ti, D), "txt": txt.reshape(B * Tt, D)}
+        xs = {s: (x if x.is_contiguous() else x.contiguous()) for s, x in xs.items()}
+        # (the small-M weight-streaming bf16 linear has no half-format columns: V then stays bf16
+        # and the attention call converts it, as on the layer path)
+        half = _C.value_half() and (fp8 or min(B * Ti, B * Tt) > 16)
+        # q|k|v of both streams straight into the joint [video | text] buffer
+        qkv = torch.empty((B * S, 3 * D), dtype=img.dtype, device=img.device)
+        for s, T, off in (("img", Ti, 0), ("txt", Tt, Ti)):
+            a, sa = _norm_in(xs[s], mods[s][0], mods[s][1], B, T, fp8)
+            _gemm(getattr(self, f"{s}_attn_qkv"), a, qkv, sa=sa, o_map=(T, S, off),
+                  f16_cols=(2 * D, 3 * D) if half else None)
+        qkv5 = qkv.view(B, S, 3, H, D // H)
+        q, k, v = qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2]
+        cos, sin = _joint_rope_table(freqs_cis[0], freqs_cis[1], Tt)
+        _C.qk_norm_rope(q, k, self.img_attn_q_norm.weight.data, self.img_attn_k_norm.weight.data,
+                        self.txt_attn_q_norm.weight.data, self.txt_attn_k_norm.weight.data, Ti,
+                        1e-6, cos, sin, True)
+        img_attn, txt_attn = self.attn(q[:, :Ti], k[:, :Ti], v[:, :Ti], q[:, Ti:], k[:, Ti:],
+                                       v[:, Ti:], value_is_half=half)
+        out = []
+        for s, T, attn in (("img", Ti, img_attn), ("txt", Tt, txt_attn)):
+            _, _, g1, sh2, sc2, g2 = mods[s]
+            a2 = attn.reshape(B * T, D)
+            a2 = a2 if a2.is_contiguous() else a2.contiguous()
+            aq, asc = _quant_in(a2, fp8)
+            y = torch.empty((B * T, D), dtype=img.dtype, device=img.device)
+            _gemm(getattr(self, f"{s}_attn_proj"), aq, y, sa=asc)
+            # x + attn_out * gate, LayerNorm, scale / shift: one pass
+            mlp_in = torch.empty_like(y)
+            resid = torch.empty_like(y)
+            _C.scale_residual_layernorm_modulate(mlp_in, resid, xs[s], y, g1, sh2, sc2, B, T, 1e-6)
+            mlp = getattr(self, f"{s}_mlp")
+            mq, msc = _quant_in(mlp_in, fp8)
+            h = torch.empty((B * T, mlp.fc_in.weight.shape[0]), dtype=img.dtype, device=img.device)
+            _gemm(mlp.fc_in, mq, h, sa=msc, act=1)                         # GELU in the epilogue
+            hq, hsc = _quant_in(h, fp8)
+            o = torch.empty_like(y)
+            _gemm(mlp.fc_out, hq, o, sa=hsc, residual=resid, gate=g2, gate_rows=T)   # + gated residual
+            out.append(o.view(B, T, D))
+        return out[0], out[1]
 
     def _qkv(self, s: str, x_mod: torch.Tensor):
         qkv, _ = getattr(self, f"{s}_attn_qkv")(x_mod)
@@ -140,6 +258,9 @@ class MMDoubleStreamBlock(nn.Module):
 
     def forward(self, img: torch.Tensor, txt: torch.Tensor, vec: torch.Tensor,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        kind = self._fused_kind() if self.fused else None
+        if kind is not None:
+            return self._forward_fused(img, txt, vec, freqs_cis, kind)
         (i_sh1, i_sc1, i_g1, i_sh2, i_sc2, i_g2) = torch.chunk(self.img_mod(vec), 6, dim=-1)
         (t_sh1, t_sc1, t_g1, t_sh2, t_sc2, t_g2) = torch.chunk(self.txt_mod(vec), 6, dim=-1)
         Ti, Tt = img.shape[1], txt.shape[1]
@@ -193,9 +314,48 @@ class MMSingleStreamBlock(nn.Module):
         self.attn = UlyssesAttention(num_heads=num_attention_heads, head_size=head_dim, causal=False,
                                      supported_attention_backends=supported_attention_backends,
                                      prefix=f"{prefix}.attn", group=sp_group)
+        self.fused = True   # False: the layer path (same bits)
+
+    def _forward_fused(self, x, vec, txt_len: int, freqs_cis, kind: str):
+        fp8 = kind == "fp8"
+        B, S, D = x.shape
+        H, Ti, Dm = self.num_attention_heads, S - txt_len, self.mlp_hidden_dim
+        shift, scale, gate = (_rows_per_sample(m, B, D, "modulation")
+                              for m in self.modulation(vec).chunk(3, dim=-1))
+        x2 = x.reshape(B * S, D)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        a, sa = _norm_in(x2, shift, scale, B, S, fp8)
+        half = _C.value_half() and (fp8 or B * S > 16)
+        # linear1 as two launches on one activation: q|k|v (V in half), and the MLP columns with
+        # tanh-GELU in the epilogue, written where linear2 reads them
+        qkv = torch.empty((B * S, 3 * D), dtype=x.dtype, device=x.device)
+        _gemm(self.linear1, a, qkv, sa=sa, n0=0, n1=3 * D, f16_cols=(2 * D, 3 * D) if half else None)
+        combined = torch.empty((B * S, D + Dm), dtype=x.dtype, device=x.device)
+        _gemm(self.linear1, a, combined[:, D:], sa=sa, n0=3 * D, n1=3 * D + Dm, act=1)
+        qkv5 = qkv.view(B, S, 3, H, D // H)
+        q, k, v = qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2]
+        cos, sin = _joint_rope_table(freqs_cis[0], freqs_cis[1], txt_len)
+        w_q, w_k = self.q_norm.weight.data, self.k_norm.weight.data
+        _C.qk_norm_rope(q, k, w_q, w_k, w_q, w_k, 0, 1e-6, cos, sin, True)
+        # on one rank the kernel writes linear2's attention columns itself
+        dst = combined.view(B, S, D + Dm)[:, :, :D].unflatten(-1, (H, D // H))
+        img_o, txt_o = self.attn(q[:, :Ti], k[:, :Ti], v[:, :Ti], q[:, Ti:], k[:, Ti:], v[:, Ti:],
+                                 value_is_half=half, out=dst)
+        if img_o.data_ptr() != dst.data_ptr():        # the result came out of an exchange
+            dst[:, :Ti] = img_o
+            dst[:, Ti:] = txt_o
+        cq, cs = _quant_in(combined, fp8)
+        out = torch.empty((B * S, D), dtype=x.dtype, device=x.device)
+        _gemm(self.linear2, cq, out, sa=cs, residual=x2, gate=gate, gate_rows=S)
+        return out.view(B, S, D)
 
     def forward(self, x: torch.Tensor, vec: torch.Tensor, txt_len: int,
                 freqs_cis: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+        kind = None
+        if self.fused and _lin_kind(self.linear1) == _lin_kind(self.linear2):
+            kind = _lin_kind(self.linear1)
+        if kind is not None:
+            return self._forward_fused(x, vec, txt_len, freqs_cis, kind)
         shift, scale, gate = self.modulation(vec).chunk(3, dim=-1)
         lin1, _ = self.linear1(self.input_norm_scale_shift(x, shift, scale))
         B, S = lin1.shape[:2]

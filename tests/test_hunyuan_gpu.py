@@ -70,6 +70,32 @@ def test_single_stream_block_vs_oracle(device, fp8):
     assert e <= (2e-2 if fp8 else 4e-3)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("B", [1, 2])
+def test_fused_block_schedule_equals_the_layer_path(device, fp8, B):
+    """The blocks' fused schedule (joint q|k|v buffer through row maps, V written in half by the
+    projection, GELU and the gated residual in GEMM epilogues, LayerNorm + modulation + fp8
+    quantisation in one pass, attention writing linear2's input in place) against the same
+    blocks run module by module: the same kernels on the same values, so the same bits."""
+    img, txt, vec, cos, sin = _inputs(B, 96, 24, seed=4)
+    d = lambda t: t.to(device)  # noqa: E731
+    fr = (d(cos), d(sin))
+    blk, _ = _build(MMDoubleStreamBlock, device, fp8, "double_blocks.0")
+    with torch.no_grad():
+        assert blk.fused and blk._fused_kind() == ("fp8" if fp8 else "bf16")
+        fi, ft = blk(d(img), d(txt), d(vec), fr)
+        blk.fused = False
+        li, lt = blk(d(img), d(txt), d(vec), fr)
+    assert torch.equal(fi, li) and torch.equal(ft, lt)
+    sblk, _ = _build(MMSingleStreamBlock, device, fp8, "single_blocks.0")
+    x = torch.cat([img, txt], dim=1)
+    with torch.no_grad():
+        fo = sblk(d(x), d(vec), 24, fr)
+        sblk.fused = False
+        lo = sblk(d(x), d(vec), 24, fr)
+    assert torch.equal(fo, lo)
+
+
 def test_text_rows_are_not_rotated(device):
     """The joint rotation table's identity rows leave the text q / k bit for bit at their
     RMSNorm values: rotating the video angles must not change the text output's dependence
