@@ -73,8 +73,9 @@ def _a2a(recv: torch.Tensor, send: torch.Tensor, group) -> None:
 
 
 def gather_latents(local: torch.Tensor, counts: Sequence[int], group=None) -> Optional[torch.Tensor]:
-    """Gather per-rank final latents [n_r, ...] to rank 0 (once per batch).  Ranks may hold
-    different request counts: pad to the maximum, all_gather, trim."""
+    """Gather per-rank final latents [n_r, ...] to rank 0 of `group` (once per batch): a
+    `dist.gather`, so only rank 0 receives anything.  Ranks may hold different request counts:
+    every rank pads to the maximum, rank 0 trims."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
@@ -82,9 +83,10 @@ def gather_latents(local: torch.Tensor, counts: Sequence[int], group=None) -> Op
     pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     pad = _wire(pad, group)
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    if dist.get_rank(group) != 0:
+    root = dist.get_rank(group) == 0
+    bufs = [torch.empty_like(pad) for _ in range(world)] if root else None
+    dist.gather(pad, bufs, dst=_global_rank(group, 0), group=group)
+    if not root:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(local.device)
 
