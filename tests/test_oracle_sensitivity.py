@@ -3,16 +3,20 @@
 per-block bars of tests/test_real_width_gpu.py.
 
 The oracle (oracle/flux_oracle.py; blocks: python/sglang/multimodal_gen/runtime/models/dits/
-flux.py:499-559, 620-692) is evaluated three ways on identical block inputs:
-  base     fp32 softmax, GEMM sums in the library's order;
-  softmax  the same with an fp64 softmax(q k^T) v (strictly more accurate arithmetic);
-  permuted the same as base with every linear's K dimension walked in another order
-           (x[:, perm] @ W[:, perm]^T: the same products, another fp32 summation order --
-           what any other GEMM kernel, the HIP one included, does to the oracle's sums).
+flux.py:499-559, 620-692) is evaluated four ways on identical block inputs:
+  base      fp32 softmax, GEMM sums in the library's order;
+  softmax   the same with an fp64 softmax(q k^T) v (strictly more accurate arithmetic);
+  permuted  the same as base with every linear's K dimension walked in another order
+            (x[:, perm] @ W[:, perm]^T: the same products, another fp32 summation order --
+            what any other GEMM kernel, the HIP one included, does to the oracle's sums);
+  flash     permuted, and the softmax probabilities rounded to 16 bits before P.V as every
+            flash-attention kernel does: to bf16 (FA3 / aiter, the kernels the reference's own
+            attention backends call, layers/attention/backends/flash_attn.py:517-532,
+            aiter.py:84-92) and to IEEE half (the HIP kernel here).
 Each is a legitimate rendering of the reference.  Whatever separates them is rounding noise
 that no implementation can be asked to stay under; the GPU bars are read against it.
 
-CPU only, about two minutes on 8 cores.
+CPU only, about three minutes on 8 cores.
 """
 import pytest
 import torch
@@ -92,6 +96,22 @@ def _attention_fp64(q, k, v, scale=None, return_lse=False):
     return out
 
 
+def _attention_p16(dtype):
+    """softmax in fp32, probabilities rounded to `dtype`, P.V accumulated in fp32."""
+    def fn(q, k, v, scale=None, return_lse=False):
+        out = torch.empty_like(q)
+        sc = scale or q.shape[-1] ** -0.5
+        for h in range(q.shape[2]):
+            qf, kf, vf = (x[:, :, h].float() for x in (q, k, v))
+            s_ = qf @ kf.transpose(-1, -2) * sc
+            m = s_.amax(-1, keepdim=True)
+            e = torch.exp(s_ - m)
+            p = e.to(dtype).float()                         # the flash kernels' rounding point
+            out[:, :, h] = ((p @ vf) / e.sum(-1, keepdim=True)).to(q.dtype)
+        return out
+    return fn
+
+
 @pytest.mark.parametrize("fp8", [False, True])
 def test_block_floor_at_real_width(fp8):
     torch.manual_seed(0)
@@ -121,6 +141,18 @@ def test_block_floor_at_real_width(fp8):
             O.attention = keep
         res["softmax"] = dict(d=(rel_l2(fe, d_enc), rel_l2(fh, d_hid)),
                               s=(rel_l2(fse, s_enc), rel_l2(fsh, s_hid)))
+        # (LayerNorm and tanh-GELU evaluated in fp64 on top of this were measured too: they move
+        # the figures by less than 5e-5, so elementwise kernels are not where a block's
+        # deviation comes from)
+        for name, dt in (("flash_bf16", torch.bfloat16), ("flash_half", torch.float16)):
+            try:
+                O.attention = _attention_p16(dt)
+                xe, xh = perm.double_block(0, hid, enc, temb, freqs)
+                xse, xsh = perm.single_block(0, d_hid, d_enc, temb, freqs)
+            finally:
+                O.attention = keep
+            res[name] = dict(d=(rel_l2(xe, d_enc), rel_l2(xh, d_hid)),
+                             s=(rel_l2(xse, s_enc), rel_l2(xsh, s_hid)))
     for name, r in res.items():
         print(f"real-width floor fp8={fp8} {name}: double (txt {r['d'][0]:.2e}, img {r['d'][1]:.2e}) "
               f"single (txt {r['s'][0]:.2e}, img {r['s'][1]:.2e})")
@@ -130,7 +162,11 @@ def test_block_floor_at_real_width(fp8):
     from tests.real_width_bars import BAR
 
     for name, r in res.items():
+        if name == "flash_bf16":
+            continue   # the reference's own flash kernels are COARSER than the bars (reported only)
         for kind in ("d", "s"):
             for v in r[kind]:
                 assert v <= BAR[(kind, fp8)], (name, kind, v)
     assert max(res["permuted"]["d"]) >= 1e-4
+    # the half-precision P.V product of the HIP kernel is the finer of the two flash renderings
+    assert max(res["flash_half"]["d"]) <= max(res["flash_bf16"]["d"])
