@@ -800,6 +800,232 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   }
 }
 
+// ---- fp8 W8A8 GEMM, 256 x 256 tiles, operands through a five-slot LDS ring -------------
+// What bounds the 256 x 256 fp8 tile is not its MFMAs (2048 clocks per 128-byte K tile and
+// SIMD) but the L2 -> LDS fill: 64 KiB per K tile and CU arrive at 25-30 B/clk, ~2200 clocks,
+// and in a two-stage scheme (everything requested behind one barrier, everything awaited in
+// front of the next) the fill pipe also runs EMPTY around every barrier -- measured with the
+// MFMAs removed, a K tile still took 2400-3000 clocks; with the refill removed, 2500.
+// Here an operand tile of one K tile (256 rows x 128 B = 32 KiB) is an item of a stream
+//     A_0 W_0 A_1 W_1 A_2 ...      item t lives in slot t mod 5 (5 x 32 KiB = all of the LDS)
+// and behind the barrier that opens K tile g the wave requests W_{g+1} and A_{g+2} (into the
+// slots A_{g-1} and W_{g-1} have just left) and waits, in front of the next barrier, with
+// vmcnt(4): for everything but its four youngest pieces, i.e. A_{g+2} stays in flight ACROSS
+// the barrier and the fill pipe never drains.  The stream runs on across output tiles (the
+// activation pointers move to the workgroup's next output tile two K tiles before the end, the
+// weight pointers one), so there is no start-up per output tile either; when no tile follows,
+// the stream re-reads the current tile's first K tiles (valid addresses, unused results).
+// The epilogue borrows the two slots the last K tile has just left (scratch, tables); the
+// barrier that follows it refills them.  Wave tiles, fragment layout, MFMA order and epilogue
+// are those of gemm_kernel<1, 4, 2, 2, 4, ..., MF16>: same bits.
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
+  constexpr int NW = 8, WAVES_M = 4, TM = 2, TN = 4, BM = 256, BN = 256;
+  constexpr int SLOT = 256 * 128;
+  constexpr int NSLOT = 5;
+  constexpr int NP = 4;  // 1-KiB LDS-DMA pieces per wave and item
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  auto tile_of = [&](int vb, int& m0, int& n0) {  // the walk of gemm_kernel
+    const int q = nwg >> 3, rr = nwg & 7, xcd = vb & 7;
+    const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (vb >> 3);
+    const int group_sz = p.group * tiles_n;
+    const int gidx = bid / group_sz;
+    const int first_m = gidx * p.group;
+    const int gm = min(tiles_m - first_m, p.group);
+    const int in_g = bid - gidx * group_sz;
+    m0 = (first_m + in_g % gm) * BM;
+    n0 = (in_g / gm) * BN;
+  };
+
+  // per-lane sources of the two streams: piece = wave + 8 i holds rows piece * 8 .. + 7 of the
+  // operand tile, 16-byte chunks swizzled by the row as in gemm_kernel
+  const unsigned char* srca[NP];
+  const unsigned char* srcw[NP];
+  auto set_src_a = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = (wave + i * NW) * 8 + (lane >> 3);
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      const int64_t gm = map_row32(min(m0 + row, p.M - 1), (int)p.a_map.rows_per_batch,
+                                   p.a_map.batch_rows, p.a_map.row_offset);
+      srca[i] = p.a + gm * p.lda_b + lc * 16;
+    }
+  };
+  auto set_src_w = [&](int n0) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = (wave + i * NW) * 8 + (lane >> 3);
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      srcw[i] = p.w + (int64_t)min(n0 + row, p.N - 1) * p.ldw_b + lc * 16;
+    }
+  };
+  auto piece_a = [&](int slot, int i) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)srca[i],
+                                     (lds_ptr_t)(smem + slot * SLOT + (wave + i * NW) * 1024), 16, 0, 0);
+    srca[i] += 128;
+  };
+  auto piece_w = [&](int slot, int i) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)srcw[i],
+                                     (lds_ptr_t)(smem + slot * SLOT + (wave + i * NW) * 1024), 16, 0, 0);
+    srcw[i] += 128;
+  };
+
+  float sb_reg = 1.f, sa_reg = 1.f;
+  unsigned short bias_reg = 0;
+  auto load_tables = [&](int m0, int n0) {
+    if (tid < BN) {
+      const int n = n0 + tid;
+      sb_reg = n < p.N ? p.sb[n] : 1.f;
+      bias_reg = (p.bias && n < p.N) ? p.bias[n] : (unsigned short)0;
+    }
+    if (tid < BM) {
+      const int mc = min(m0 + tid, p.M - 1);
+      sa_reg = p.sa[map_row32(mc, (int)p.a_map.rows_per_batch, p.a_map.batch_rows,
+                              p.a_map.row_offset)];
+    }
+  };
+
+  const int l16 = lane & 15, q16 = lane >> 4, swz16 = (l16 >> 1) & 7;
+  const int x_off = (wm * TM * 32 + l16) * 128, w_off = (wn * TN * 32 + l16) * 128;
+  const int c0 = (q16 ^ swz16) << 4, c1 = ((q16 + 4) ^ swz16) << 4;
+  const int unit_scale = 0x7f7f7f7f;
+
+  auto next_slot = [](int s, int by) {
+    s += by;
+    return s >= NSLOT ? s - NSLOT : s;
+  };
+
+  int vb = blockIdx.x;
+  int m0, n0;
+  tile_of(vb, m0, n0);
+  int nm0 = m0, nn0 = n0, nvb = vb;
+  bool more = false;
+  // start of the stream: A_0, W_0, A_1 (at least two K tiles per output tile: launch precondition)
+  set_src_a(m0);
+  set_src_w(n0);
+  load_tables(m0, n0);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) piece_a(0, i);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) piece_w(1, i);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) piece_a(2, i);
+  int sl = 0;  // slot of the current K tile's activation item (its weight item: the next slot)
+
+  while (true) {
+    f32x4 acc[TN * 2][TM * 2];
+#pragma unroll
+    for (int i = 0; i < TN * 2; ++i)
+#pragma unroll
+      for (int j = 0; j < TM * 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+      // this K tile's two items have landed (everything but the youngest item, A of the next K
+      // tile; after an epilogue its stores are in the count as well: wait for all of it once)
+      // (s_barrier itself, not __syncthreads(): the fence of the latter makes the compiler drain
+      // vmcnt to zero in front of every barrier, which is exactly what the ring is there to avoid;
+      // the waits a barrier over LDS needs are spelled out)
+      if (kt == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // the streams move on to the next output tile: activations at K tile ktiles - 2 (they run
+      // two K tiles ahead), weights at ktiles - 1
+      if (kt + 2 == p.ktiles) {
+        nvb = vb + (int)gridDim.x;
+        more = nvb < nwg;
+        nm0 = m0;
+        nn0 = n0;
+        if (more) tile_of(nvb, nm0, nn0);
+        set_src_a(nm0);
+      }
+      if (kt + 1 == p.ktiles) set_src_w(nn0);
+      const int s_w1 = next_slot(sl, 3), s_a2 = next_slot(sl, 4);
+      const unsigned char* xb = smem + sl * SLOT + x_off;
+      const unsigned char* wb = smem + next_slot(sl, 1) * SLOT + w_off;
+      piece_w(s_w1, 0);
+      piece_w(s_w1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      i32x8 bfr[TM * 2];
+#pragma unroll
+      for (int j = 0; j < TM * 2; ++j) {
+        const unsigned char* pb = xb + j * 16 * 128;
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(pb + c0);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(pb + c1);
+        bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int ig = 0; ig < TN * 2; ig += 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        i32x8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned char* pa = wb + (ig + i) * 16 * 128;
+          const i32x4 lo = *reinterpret_cast<const i32x4*>(pa + c0);
+          const i32x4 hi = *reinterpret_cast<const i32x4*>(pa + c1);
+          af[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // the rest of the refill between the MFMA blocks: weights first (due at the next
+          // barrier), then the activation item that stays in flight across it
+          const int blk = ig + i;
+          if (blk == 1) {
+            piece_w(s_w1, 2);
+            piece_w(s_w1, 3);
+          } else if (blk >= 2 && blk < 2 + NP) {
+            piece_a(s_a2, blk - 2);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < TM * 2; ++j)
+            acc[ig + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                af[i], bfr[j], acc[ig + i][j], 0, 0, 0, unit_scale, 0, unit_scale);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      sl = next_slot(sl, 2);
+    }
+
+    // the two slots of the last K tile are free once every wave is here: scratch in the
+    // activation slot, tables in the weight slot
+    const int s_scr = next_slot(sl, NSLOT - 2), s_tab = next_slot(sl, NSLOT - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    float* sb_l = reinterpret_cast<float*>(smem + s_tab * SLOT);
+    float* sa_l = sb_l + BN;
+    unsigned short* bias_l = reinterpret_cast<unsigned short*>(sa_l + BM);
+    if (tid < BN) {
+      sb_l[tid] = sb_reg;
+      bias_l[tid] = bias_reg;
+    }
+    if (tid < BM) sa_l[tid] = sa_reg;
+    const int em0 = m0, en0 = n0;
+    if (more) load_tables(nm0, nn0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tables visible
+    asm volatile("" ::: "memory");
+    gemm_epilogue16<1, 4, 2, 2, 4>(p, acc, smem + s_scr * SLOT + wave * 4096, sb_l, sa_l, bias_l, em0,
+                                   en0, wave, lane);
+    if (!more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail of the stream
+      break;
+    }
+    vb = nvb;
+    m0 = nm0;
+    n0 = nn0;
+  }
+}
+
 // ---- small-M (<= 16 rows) bf16 linear: pure weight streaming ------------------
 // out[m][n] = act( sum_k x[m][k] w[n][k] + bias[n] ).  One wavefront per output
 // channel pair; lanes split K in 16-byte chunks, fp32 accumulate, shuffle reduce.
@@ -922,6 +1148,30 @@ int launch_gemm(const GemmParams& p, hipStream_t st) {
   return MI355_OK;
 }
 
+int launch_gemm_ring(const GemmParams& p, hipStream_t st) {
+  constexpr int LDS = 5 * 256 * 128;  // all of a CU's LDS
+  static std::atomic<unsigned long long> attr_devices{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
+  if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      mi355_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
+      return MI355_EHIP;
+    }
+    attr_devices.fetch_or(dev_bit, std::memory_order_release);
+  }
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
+  GemmParams q = p;
+  q.group = tiles_n <= 16 ? 2 : 8;
+  dim3 grid((unsigned)min(tiles_m * tiles_n, resident_workgroups(LDS))), block(512);
+  hipLaunchKernelGGL(gemm_ring_kernel, grid, block, LDS, st, q);
+  MI355_CHECK_LAUNCH("gemm_ring");
+  return MI355_OK;
+}
+
 // 256x256 tiles (one workgroup per CU) or 128x128 (two per CU)?  Small ones when the big ones
 // would not cover three quarters of the CUs; otherwise whichever fills its rounds better, the small tile counted at its measured relative speed (0.8 of the big one for fp8, 0.7
 // for bf16): 2048 x 9216 fp8 is 288 big tiles = 1.125 rounds (93 us) but 2.25 rounds of small ones
@@ -1031,9 +1281,13 @@ int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hip
   // element of K = 15360 outputs) and 2-6 % (fp8) / 5-8 % (bf16) less time on the Flux shapes --
   // the chip is power-capped under these kernels and holds a higher clock with them.  bf16 adds
   // the software-pipelined K loop (same bits, 3-4 % less time).
-  if (fp8)
+  if (fp8) {
+    // big tiles through the five-slot ring (same bits as the two-stage kernel, which remains for
+    // a single K tile): 3-5 % less time per GEMM, whole step 192.2 -> 188.5 ms in a same-box A/B
+    if (big && p.ktiles >= 2) return launch_gemm_ring(p, st);
     return big ? launch_gemm<1, 4, 2, 2, 4, false, false, true>(p, st)
                : launch_gemm<1, 2, 2, 2, 2, false, false, true>(p, st);
+  }
   return big ? launch_gemm<0, 4, 2, 2, 4, false, false, true, true>(p, st)
              : launch_gemm<0, 2, 2, 2, 2, false, false, true, true>(p, st);
 }

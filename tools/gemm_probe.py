@@ -68,3 +68,9 @@ if mode == "gelu":
         for act in (0, 1):
             print(f"act={act}", end="  ")
             bench(fp8, M, N, K, act=act)
+if mode == "ksweep":
+    # 1024 big tiles = 4 full rounds on 256 CUs; time is linear in K: the slope is the K loop's
+    # cost per 128-byte K tile, the intercept what a tile costs outside it (epilogue, seams)
+    for fp8 in (True, False):
+        for K in (1024, 2048, 4096, 8192):
+            bench(fp8, 16384, 4096, K)
