@@ -168,6 +168,27 @@ def test_fp8_scaled_mm_exact_on_integer_data(device):
     assert torch.equal(out.float().cpu(), (a @ w.t()).bfloat16().float())
 
 
+@pytest.mark.parametrize("K", [256, 384, 3072])
+def test_fp8_scaled_mm_big_tiles_through_the_ring(device, K):
+    """Outputs of >= 192 tiles of 256 x 256 take the five-slot-ring kernel (K >= 256).  Ragged
+    M and N (partial last tiles), two, three and 24 K tiles: against the oracle, and -- same
+    MFMAs in the same K order -- bit for bit against the small-tile kernel run on a slice."""
+    M, N = 17 * 256 + 19, 12 * 256 + 8
+    a = (torch.randn(M, K, generator=g(51)) * 3).clamp(-448, 448).to(FP8)
+    w = (torch.randn(N, K, generator=g(52)) * 3).clamp(-448, 448).to(FP8)
+    sa = torch.rand(M, generator=g(53)) * 0.02 + 1e-3
+    sb = torch.rand(N, generator=g(54)) * 0.02 + 1e-3
+    b = torch.randn(N, generator=g(55)).bfloat16()
+    ad, wd, sad, sbd, bd = (t.to(device) for t in (a, w, sa, sb, b))
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=device)
+    _C.fp8_scaled_mm(ad, wd, sad, sbd, bd, out)
+    _gemm_close(out, ops.fp8_scaled_mm(a, w, sa, sb, b))
+    for r0, rows in ((0, 256), (1000, 130), (M - 19, 19)):
+        part = torch.empty(rows, N, dtype=torch.bfloat16, device=device)
+        _C.fp8_scaled_mm(ad[r0:r0 + rows], wd, sad[r0:r0 + rows], sbd, bd, part)
+        assert torch.equal(part, out[r0:r0 + rows]), (K, r0)
+
+
 def test_fp8_scaled_mm_rejects_unaligned(device):
     a = torch.zeros(8, 100, dtype=FP8, device=device)
     w = torch.zeros(16, 100, dtype=FP8, device=device)

@@ -1,8 +1,11 @@
 """Where a GEMM tile's time goes: an INSTRUMENTED build of csrc/gemm.hip whose workgroups
 stamp the 100-MHz wall clock at four points of every output tile (K loop begins, K loop ends,
-epilogue begins, epilogue ends) into a device array; this script builds it into
-tools/probes/bin/libmi355dit_timing.so (never the product library), runs one launch per shape
-and prints per-phase medians plus how far apart the workgroups of a round are.
+epilogue begins, epilogue ends; the shader-clock counter as well around the K loop) into a
+device array; this script builds it into tools/probes/bin/libmi355dit_timing.so (never the
+product library), runs one launch per shape and prints per-phase medians, the clock inside the
+K loop and how far apart the workgroups of a round are.  Extra compiler flags after `build`
+select ablations of the ring kernel (timing only, the results are wrong): -DABL_RING_NOMFMA
+(refill + barrier + fragment reads alone), -DABL_RING_NODMA (no refill).
 
     python tools/probes/gemm_phase_timing.py build      # here, no GPU
     python tools/probes/gemm_phase_timing.py run         # on the GPU box
@@ -48,29 +51,11 @@ def build():
         "    __syncthreads();  // tables visible\n"
         "    if (tid == 0 && tile_no < %d) g_stamp[(blockIdx.x * %d + tile_no) * 4 + 2] = wall_clock64();\n"
         "    if constexpr (MF16)" % (MAXT, MAXT))
-    rep("    if (!more) {\n      // the last tile's refill went",
+    rep("    if (!more) break;\n    vb = nvb;\n",
         "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
         "    if (tid == 0 && tile_no < %d) g_stamp[(blockIdx.x * %d + tile_no) * 4 + 3] = wall_clock64();\n"
-        "    ++tile_no;\n    if (!more) {\n      // the last tile's refill went" % (MAXT, MAXT))
-    # the 128 x 128-per-wave kernel (-DMI355_GEMM_W128 selects it): the same four stamps
-    rep("  while (true) {\n    f32x4 acc[8][8];",
-        "  int tile_no = 0;\n  while (true) {\n"
-        "    if (tid == 0 && tile_no < %d) { g_stamp[(blockIdx.x * %d + tile_no) * 4 + 0] = wall_clock64();"
-        " g_cyc[(blockIdx.x * %d + tile_no) * 2 + 0] = clock64(); }\n"
-        "    f32x4 acc[8][8];" % (MAXT, MAXT, MAXT))
-    rep("    // park the tables, run the epilogue out of its own LDS area\n",
-        "    if (tid == 0 && tile_no < %d) { g_stamp[(blockIdx.x * %d + tile_no) * 4 + 1] = wall_clock64();"
-        " g_cyc[(blockIdx.x * %d + tile_no) * 2 + 1] = clock64(); }\n" % (MAXT, MAXT, MAXT))
-    rep("    __syncthreads();  // tables visible\n    gemm_epilogue16<1, 2, 2, 4, 4, true>",
-        "    __syncthreads();  // tables visible\n"
-        "    if (tid == 0 && tile_no < %d) g_stamp[(blockIdx.x * %d + tile_no) * 4 + 2] = wall_clock64();\n"
-        "    gemm_epilogue16<1, 2, 2, 4, 4, true>" % (MAXT, MAXT))
-    rep("    if (!more) {\n      // the refill of the last two K tiles",
-        "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n"
-        "    if (tid == 0 && tile_no < %d) g_stamp[(blockIdx.x * %d + tile_no) * 4 + 3] = wall_clock64();\n"
-        "    ++tile_no;\n"
-        "    if (!more) {\n      // the refill of the last two K tiles" % (MAXT, MAXT))
-    # the ring kernel (-DMI355_GEMM_RING): stamps, and -DABL_RING_NOMFMA
+        "    ++tile_no;\n    if (!more) break;\n    vb = nvb;\n" % (MAXT, MAXT))
+    # the ring kernel: stamps, and -DABL_RING_NOMFMA (its K loop without the MFMAs)
     rep("  while (true) {\n    f32x4 acc[TN * 2][TM * 2];",
         "  int tile_no = 0;\n  while (true) {\n"
         "    if (tid == 0 && tile_no < %d) { g_stamp[(blockIdx.x * %d + tile_no) * 4 + 0] = wall_clock64();"
@@ -96,45 +81,19 @@ def build():
                 af[i], bfr[j], acc[ig + i][j], 0, 0, 0, unit_scale, 0, unit_scale);
 #endif
           __builtin_amdgcn_sched_barrier(0);""")
-    # -DABL_W128_NODMA / -DABL_W128_NOMFMA: the same two ablations of the 128 x 128-per-wave kernel
-    rep("""    if constexpr (k >= 0) {
-      stage_piece(refill_stage, k);""", """    if constexpr (k >= 0) {
-#ifndef ABL_W128_NODMA
-#ifdef ABL_W128_HALFDMA
-      if constexpr (k < 8)
+    # -DABL_RING_NODMA: the ring without its refill
+    rep("""  auto piece_a = [&](int slot, int i) {
+    __builtin_amdgcn_global_load_lds(""", """  auto piece_a = [&](int slot, int i) {
+#ifdef ABL_RING_NODMA
+    if (slot >= 0) return;
 #endif
-#ifdef ABL_W128_QUARTERDMA
-      if constexpr (k < 4)
+    __builtin_amdgcn_global_load_lds(""")
+    rep("""  auto piece_w = [&](int slot, int i) {
+    __builtin_amdgcn_global_load_lds(""", """  auto piece_w = [&](int slot, int i) {
+#ifdef ABL_RING_NODMA
+    if (slot >= 0) return;
 #endif
-      stage_piece(refill_stage, k);
-#endif""")
-    rep("""  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, v[" AALL "], v[" BALL "], %0, %3, %3 "     \\
-               "op_sel_hi:[0,0,0]"  """.rstrip() , """  asm volatile(W128_MFMA_TEXT "%0, v[" AALL "], v[" BALL "], %0, %3, %3 "     \\
-               "op_sel_hi:[0,0,0]"  """.rstrip())
-    rep("#define W128_LDS2(var, LO, HI, ALL, alo, ahi, off)", """#ifdef ABL_W128_NOMFMA
-#define W128_MFMA_TEXT "; "
-#else
-#define W128_MFMA_TEXT "v_mfma_scale_f32_16x16x128_f8f6f4 "
-#endif
-#define W128_LDS2(var, LO, HI, ALL, alo, ahi, off)""")
-    # -DABL_NOMFMA: the 8-wave fp8 K loop without its MFMAs (fragments still read): what the
-    # refill + barrier + LDS reads take on their own
-    rep("""              acc[ig + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                  af[i], bfr[j], acc[ig + i][j], 0, 0, 0, unit_scale, 0, unit_scale);
-            __builtin_amdgcn_sched_barrier(0);""", """#ifdef ABL_NOMFMA
-              asm volatile("" ::"v"(af[i]), "v"(bfr[j]));
-#else
-              acc[ig + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                  af[i], bfr[j], acc[ig + i][j], 0, 0, 0, unit_scale, 0, unit_scale);
-#endif
-            __builtin_amdgcn_sched_barrier(0);""")
-    # -DABL_NODMA: the spread refill of the fp8 K loop is skipped (timing only: wrong results)
-    rep("""              if ((ig + i) * SPREAD_PER + q < NPIECE) stage_piece(cur ^ 1, (ig + i) * SPREAD_PER + q);""",
-        """              if ((ig + i) * SPREAD_PER + q < NPIECE) {
-#ifndef ABL_NODMA
-                stage_piece(cur ^ 1, (ig + i) * SPREAD_PER + q);
-#endif
-              }""")
+    __builtin_amdgcn_global_load_lds(""")
     os.makedirs("/tmp/gemm_timing", exist_ok=True)
     src = "/tmp/gemm_timing/gemm_timing.hip"
     open(src, "w").write(s)
