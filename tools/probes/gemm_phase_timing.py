@@ -60,7 +60,7 @@ def build():
         "  int tile_no = 0;\n  while (true) {\n"
         "    if (tid == 0 && tile_no < %d) { g_stamp[(blockIdx.x * %d + tile_no) * 4 + 0] = wall_clock64();"
         " g_cyc[(blockIdx.x * %d + tile_no) * 2 + 0] = clock64(); }\n"
-        "    f32x4 acc[TN * 2][TM * 2];" % (MAXT, MAXT, MAXT))
+        "    f32x4 acc[TN * 2][TM * 2];" % (MAXT, MAXT, MAXT), count=s.count("  while (true) {\n    f32x4 acc[TN * 2][TM * 2];"))
     rep("    const int s_scr = next_slot(sl, NSLOT - 2), s_tab = next_slot(sl, NSLOT - 1);\n",
         "    if (tid == 0 && tile_no < %d) { g_stamp[(blockIdx.x * %d + tile_no) * 4 + 1] = wall_clock64();"
         " g_cyc[(blockIdx.x * %d + tile_no) * 2 + 1] = clock64(); }\n"
@@ -71,7 +71,8 @@ def build():
     rep("    if (!more) {\n      asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");  // the unused tail",
         "    if (tid == 0 && tile_no < %d) g_stamp[(blockIdx.x * %d + tile_no) * 4 + 3] = wall_clock64();\n"
         "    ++tile_no;\n"
-        "    if (!more) {\n      asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");  // the unused tail" % (MAXT, MAXT))
+        "    if (!more) {\n      asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");  // the unused tail" % (MAXT, MAXT),
+        count=s.count("    if (!more) {\n      asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");  // the unused tail"))
     rep("""            acc[ig + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
                 af[i], bfr[j], acc[ig + i][j], 0, 0, 0, unit_scale, 0, unit_scale);
           __builtin_amdgcn_sched_barrier(0);""", """#ifdef ABL_RING_NOMFMA
@@ -125,6 +126,8 @@ def run():
               (False, 16384, 12288, 3072), (False, 16384, 3072, 12288)]
     if os.environ.get("TIMING_FP8_ONLY"):
         shapes = shapes[:1] + shapes[2:3]
+    if os.environ.get("TIMING_BF16_ONLY"):
+        shapes = shapes[3:]
     for fp8, M, N, K in shapes:
         if fp8:
             a = (torch.randn(M, K, device=dev) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
