@@ -573,10 +573,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
               asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
               __syncthreads();
               if (kt + 2 < p.ktiles) stage(g & 1);
-              xa0 ^= STAGE_BYTES;
-              xa1 ^= STAGE_BYTES;
-              wa0 ^= STAGE_BYTES;
-              wa1 ^= STAGE_BYTES;
+              {
+                // the other stage (a stage is not a power of two for every tile shape)
+                const unsigned nb = lds0 + ((g + 1) & 1) * STAGE_BYTES;
+                xa0 = nb + x_row_off16 + coff16_0;
+                xa1 = nb + x_row_off16 + coff16_1;
+                wa0 = nb + w_row_off16 + coff16_0;
+                wa1 = nb + w_row_off16 + coff16_1;
+              }
 #pragma unroll
               for (int j = 0; j < TM * 2; ++j) MI355_LDS_READ(bfb[0][j], xa0, j * 16 * 128);
 #pragma unroll
@@ -1186,6 +1190,13 @@ bool use_big_tile(int64_t M, int64_t N, bool fp8) {
   return eff_b >= eff_s * (fp8 ? 0.8 : 0.7);
 }
 
+// 128x64 tiles instead of 128x128: when even the small tiles leave half of the CUs without one
+// (M = 512 text rows x N = 3072 is 96 tiles of 128x128 on 256 CUs, each walking the whole K)
+bool use_narrow_tile(int64_t M, int64_t N) {
+  const int cus = resident_workgroups(128 * 1024);
+  return ((M + 127) / 128) * ((N + 127) / 128) * 2 <= cus;
+}
+
 int check_common(const mi355_linear_args* a, const char* who) {
   MI355_REQUIRE(a->M == 0 || (a->a && a->w && a->out), "%s: null pointer", who);
   MI355_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "%s: bad shape M=%ld N=%ld K=%ld", who,
@@ -1270,6 +1281,9 @@ int build_params(const mi355_linear_args* a, GemmParams& p) {
 }
 
 int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hipStream_t st) {
+  if (!big && !block_scale && !p.out_f16 && use_narrow_tile(p.M, p.N))
+    return fp8 ? launch_gemm<1, 4, 1, 1, 2, false, false, true>(p, st)
+               : launch_gemm<0, 4, 1, 1, 2, false, false, true, true>(p, st);
   // half output is an interface-compatibility mode, not a hot path: one tile class serves it
   if (p.out_f16)
     return block_scale ? launch_gemm<1, 2, 2, 2, 2, true, true>(p, st)
