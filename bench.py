@@ -701,6 +701,9 @@ def main():
                                   + (fl["bf16"] + fl["attn"]) / (PEAK_BF16_TFLOPS * 1e12)) * 1e3,
         "roofline": roofline, "breakdown": breakdown, "cpu_baseline": cpu, "c4": None,
     }
+    # the step against the bound of its dtype mix (fp8 GEMMs at the fp8 peak, bf16 GEMMs and
+    # attention at the bf16 peak), beside the dominant kernel's own fraction in `roofline`
+    out["mixed_roofline_frac"] = out["mixed_roofline_min_ms"] / out["ms_per_step"]
     if want_c4:
         # The headline line above is complete; the fixed-size CFG job adds to it.  Whatever
         # happens in there (an exception here, a rank that died and left the others in a
