@@ -189,6 +189,39 @@ def test_fp8_scaled_mm_big_tiles_through_the_ring(device, K):
         assert torch.equal(part, out[r0:r0 + rows]), (K, r0)
 
 
+@pytest.mark.parametrize("gelu", [False, True])
+def test_ring_gemm_with_row_maps_gate_and_half_columns(device, gelu):
+    """The ring kernel behind the fused epilogues: joint-buffer row maps whose batches do not end
+    on tile borders, then either gate / residual or tanh-GELU with a range of half-format output
+    columns -- bit for bit what the small-tile kernel gives when each batch is a call of its own."""
+    B, Ti, Tt, K, N = 2, 2300, 60, 512, 3072
+    S = Ti + Tt
+    x = torch.randn(B * S, K, generator=g(61)).bfloat16()
+    w = (torch.randn(N, K, generator=g(62)) * K ** -0.5).bfloat16()
+    bias = (torch.randn(N, generator=g(63)) * 0.1).bfloat16().to(device)
+    gate = torch.randn(B, N, generator=g(64)).bfloat16().to(device)
+    res = torch.randn(B * S, N, generator=g(65)).bfloat16()
+    xq, xs = ops.per_token_quant_fp8(x)
+    wq, wsc = ops.quantize_weight_per_channel(w)
+    xq, xs, wq, wsc = xq.to(device), xs.to(device), wq.to(device), wsc.to(device)
+    kw = dict(N=N, K=K, lda=K, ldw=K, ldo=N, sb=wsc, bias=bias, fp8=True)
+    if gelu:
+        kw.update(act=1, f16_cols=(1024, 2048))
+    whole = res.to(device).clone()
+    extra = {} if gelu else dict(residual=whole, gate=gate, ldg=gate.stride(0), gate_rows=Ti)
+    _C.linear_ex(xq, wq, whole, M=B * Ti, sa=xs, a_map=(Ti, S, Tt), o_map=(Ti, S, Tt), **kw, **extra)
+    parts = res.to(device).clone()
+    for b in range(B):                      # 9 x 12 tiles each: the small-tile path
+        pb = parts[b * S:(b + 1) * S]
+        extra = {} if gelu else dict(residual=pb, gate=gate[b:b + 1], ldg=gate.stride(0), gate_rows=Ti)
+        _C.linear_ex(xq[b * S:(b + 1) * S], wq, pb, M=Ti, sa=xs[b * S:(b + 1) * S],
+                     a_map=(Ti, S, Tt), o_map=(Ti, S, Tt), **kw, **extra)
+    torch.cuda.synchronize()
+    assert torch.equal(whole.view(torch.int16), parts.view(torch.int16))
+    assert torch.equal(whole.view(B, S, N)[:, :Tt].cpu(), res.view(B, S, N)[:, :Tt]), "text rows untouched"
+    _C.f16_range_status(reset=True)
+
+
 def test_fp8_scaled_mm_rejects_unaligned(device):
     a = torch.zeros(8, 100, dtype=FP8, device=device)
     w = torch.zeros(16, 100, dtype=FP8, device=device)
