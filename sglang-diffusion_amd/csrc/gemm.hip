@@ -50,6 +50,7 @@ struct GemmParams {
   int64_t sa_sm, sa_sk, sb_sk, sb_sn;
   int group;  // M tiles per XCD chunk of the tile walk
   int out_f16;  // host side only: picks the instantiation whose output and bias are IEEE half
+  int split_from;  // ring kernel: tiles from this id on are run as two 128-channel halves
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -822,6 +823,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
 // The epilogue borrows the two slots the last K tile has just left (scratch, tables); the
 // barrier that follows it refills them.  Wave tiles, fragment layout, MFMA order and epilogue
 // are those of gemm_kernel<1, 4, 2, 2, 4, ..., MF16>: same bits.
+// TAIL: the launch has a partial last round that is run as half tiles (below); without it no
+// tile is ever a half and the kernel carries none of that state.
+template <bool TAIL>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
   constexpr int NW = 8, WAVES_M = 4, TM = 2, TN = 4, BM = 256, BN = 256;
   constexpr int SLOT = 256 * 128;
@@ -837,47 +841,76 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
-  auto tile_of = [&](int vb, int& m0, int& n0) {  // the walk of gemm_kernel
-    const int q = nwg >> 3, rr = nwg & 7, xcd = vb & 7;
-    const int bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (vb >> 3);
+  // The walk of gemm_kernel over the tiles of the full rounds; the tiles of a partial last round
+  // (p.split_from .. nwg - 1, when they leave at least half of the workgroups without one) are
+  // cut into a left and a right half of 128 channels, so that every workgroup has a last piece of
+  // work and that piece is short: a wave's 64 x 64 outputs then, half the MFMAs and three
+  // quarters of the staged bytes per K tile.
+  const int split_from = TAIL ? p.split_from : nwg;
+  const int nhalf = 2 * (nwg - split_from);
+  const int nvirt = split_from + nhalf;
+  auto tile_of = [&](int vb, int& m0, int& n0, bool& half) {
+    int tile;
+    int hsel = 0;
+    half = TAIL && vb >= split_from;
+    if (!half) {
+      const int q = split_from >> 3, rr = split_from & 7, xcd = vb & 7;
+      tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (vb >> 3);
+    } else {
+      const int hv = vb - split_from;
+      const int q = nhalf >> 3, rr = nhalf & 7, xcd = hv & 7;
+      const int h = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (hv >> 3);
+      tile = split_from + (h >> 1);
+      hsel = h & 1;
+    }
     const int group_sz = p.group * tiles_n;
-    const int gidx = bid / group_sz;
+    const int gidx = tile / group_sz;
     const int first_m = gidx * p.group;
     const int gm = min(tiles_m - first_m, p.group);
-    const int in_g = bid - gidx * group_sz;
+    const int in_g = tile - gidx * group_sz;
     m0 = (first_m + in_g % gm) * BM;
-    n0 = (in_g / gm) * BN;
+    n0 = (in_g / gm) * BN + hsel * (BN / 2);
   };
 
   // per-lane sources of the two streams: piece = wave + 8 i holds rows piece * 8 .. + 7 of the
   // operand tile, 16-byte chunks swizzled by the row as in gemm_kernel
-  const unsigned char* srca[NP];
-  const unsigned char* srcw[NP];
+  // (32-bit byte offsets from the operand bases: the launcher sends operands of 4 GiB and more to
+  // the two-stage kernel; eight vector registers less than per-lane pointers)
+  unsigned int srca[NP], srcw[NP];
+  // (the lane id of the once-per-tile code is re-made opaque where it is used: what the compiler
+  // would otherwise compute once in front of the tile loop and keep in registers across the K
+  // loops does not fit beside 128 accumulators and 64 fragment registers)
+  auto opaque = [](int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
   auto set_src_a = [&](int m0) {
+    const int ln = opaque(lane);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int row = (wave + i * NW) * 8 + (lane >> 3);
-      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      const int row = (wave + i * NW) * 8 + (ln >> 3);
+      const int lc = (ln & 7) ^ ((row >> 1) & 7);
       const int64_t gm = map_row32(min(m0 + row, p.M - 1), (int)p.a_map.rows_per_batch,
                                    p.a_map.batch_rows, p.a_map.row_offset);
-      srca[i] = p.a + gm * p.lda_b + lc * 16;
+      srca[i] = (unsigned int)(gm * p.lda_b + lc * 16);
     }
   };
   auto set_src_w = [&](int n0) {
+    const int ln = opaque(lane);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int row = (wave + i * NW) * 8 + (lane >> 3);
-      const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      srcw[i] = p.w + (int64_t)min(n0 + row, p.N - 1) * p.ldw_b + lc * 16;
+      const int row = (wave + i * NW) * 8 + (ln >> 3);
+      const int lc = (ln & 7) ^ ((row >> 1) & 7);
+      srcw[i] = (unsigned int)((int64_t)min(n0 + row, p.N - 1) * p.ldw_b + lc * 16);
     }
   };
   auto piece_a = [&](int slot, int i) {
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)srca[i],
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.a + srca[i]),
                                      (lds_ptr_t)(smem + slot * SLOT + (wave + i * NW) * 1024), 16, 0, 0);
     srca[i] += 128;
   };
   auto piece_w = [&](int slot, int i) {
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)srcw[i],
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.w + srcw[i]),
                                      (lds_ptr_t)(smem + slot * SLOT + (wave + i * NW) * 1024), 16, 0, 0);
     srcw[i] += 128;
   };
@@ -898,7 +931,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
   };
 
   const int l16 = lane & 15, q16 = lane >> 4, swz16 = (l16 >> 1) & 7;
-  const int x_off = (wm * TM * 32 + l16) * 128, w_off = (wn * TN * 32 + l16) * 128;
+  const int x_off = (wm * TM * 32 + l16) * 128;
+  const int w_off_full = (wn * TN * 32 + l16) * 128, w_off_half = (wn * TN * 16 + l16) * 128;
   const int c0 = (q16 ^ swz16) << 4, c1 = ((q16 + 4) ^ swz16) << 4;
   const int unit_scale = 0x7f7f7f7f;
 
@@ -909,9 +943,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
 
   int vb = blockIdx.x;
   int m0, n0;
-  tile_of(vb, m0, n0);
+  bool half;
+  tile_of(vb, m0, n0, half);
   int nm0 = m0, nn0 = n0, nvb = vb;
-  bool more = false;
+  bool more = false, nhalf_t = false;
   // start of the stream: A_0, W_0, A_1 (at least two K tiles per output tile: launch precondition)
   set_src_a(m0);
   set_src_w(n0);
@@ -919,7 +954,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < NP; ++i) piece_a(0, i);
 #pragma unroll
-  for (int i = 0; i < NP; ++i) piece_w(1, i);
+  for (int i = 0; i < NP; ++i)
+    if (i < 2 || !(TAIL && half)) piece_w(1, i);
 #pragma unroll
   for (int i = 0; i < NP; ++i) piece_a(2, i);
   int sl = 0;  // slot of the current K tile's activation item (its weight item: the next slot)
@@ -931,6 +967,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < TM * 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // one K loop per tile width (a half tile is always a workgroup's last tile): no branch inside
+    // a K tile
+    auto k_loop = [&](auto halfc) {
+      constexpr bool HALF = decltype(halfc)::value;
     for (int kt = 0; kt < p.ktiles; ++kt) {
       // this K tile's two items have landed (everything but the youngest item, A of the next K
       // tile; after an epilogue its stores are in the count as well: wait for all of it once)
@@ -945,16 +985,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
       // two K tiles ahead), weights at ktiles - 1
       if (kt + 2 == p.ktiles) {
         nvb = vb + (int)gridDim.x;
-        more = nvb < nwg;
+        more = nvb < nvirt;
         nm0 = m0;
         nn0 = n0;
-        if (more) tile_of(nvb, nm0, nn0);
+        nhalf_t = false;  // the unused tail of the stream is staged at full width
+        if (more) tile_of(nvb, nm0, nn0, nhalf_t);
+        if (!TAIL) nhalf_t = false;
         set_src_a(nm0);
       }
       if (kt + 1 == p.ktiles) set_src_w(nn0);
+      // the weight item requested here belongs to this tile, or (last K tile) to the next one
+      const bool w_item_half = TAIL && (kt + 1 == p.ktiles ? nhalf_t : HALF);
       const int s_w1 = next_slot(sl, 3), s_a2 = next_slot(sl, 4);
       const unsigned char* xb = smem + sl * SLOT + x_off;
-      const unsigned char* wb = smem + next_slot(sl, 1) * SLOT + w_off;
+      const unsigned char* wb = smem + next_slot(sl, 1) * SLOT + (HALF ? w_off_half : w_off_full);
       piece_w(s_w1, 0);
       piece_w(s_w1, 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -967,7 +1011,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
         bfr[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
-      for (int ig = 0; ig < TN * 2; ig += 4) {
+      for (int ig = 0; ig < (HALF ? TN : TN * 2); ig += 4) {  // a half tile: four weight fragments per wave
         __builtin_amdgcn_sched_barrier(0);
         i32x8 af[4];
 #pragma unroll
@@ -983,10 +1027,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
           // barrier), then the activation item that stays in flight across it
           const int blk = ig + i;
           if (blk == 1) {
-            piece_w(s_w1, 2);
-            piece_w(s_w1, 3);
-          } else if (blk >= 2 && blk < 2 + NP) {
-            piece_a(s_a2, blk - 2);
+            if (!w_item_half) {
+              piece_w(s_w1, 2);
+              piece_w(s_w1, 3);
+            }
+          } else if (blk == 2 || blk == 3) {
+            piece_a(s_a2, 2 * (blk - 2));
+            piece_a(s_a2, 2 * (blk - 2) + 1);
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -998,6 +1045,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
       }
       sl = next_slot(sl, 2);
     }
+    };
+    if (TAIL && half) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // the two slots of the last K tile are free once every wave is here: scratch in the
     // activation slot, tables in the weight slot
@@ -1018,8 +1068,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tables visible
     asm volatile("" ::: "memory");
-    gemm_epilogue16<1, 4, 2, 2, 4>(p, acc, smem + s_scr * SLOT + wave * 4096, sb_l, sa_l, bias_l, em0,
-                                   en0, wave, lane);
+    const int eln = opaque(lane);
+    if (TAIL && half)
+      gemm_epilogue16<1, 4, 2, 2, 2>(p, reinterpret_cast<f32x4(&)[TN][TM * 2]>(acc),
+                                     smem + s_scr * SLOT + wave * 4096, sb_l, sa_l, bias_l, em0, en0, wave,
+                                     eln);
+    else
+      gemm_epilogue16<1, 4, 2, 2, 4>(p, acc, smem + s_scr * SLOT + wave * 4096, sb_l, sa_l, bias_l, em0,
+                                     en0, wave, eln);
     if (!more) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the unused tail of the stream
       break;
@@ -1027,6 +1083,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams p) {
     vb = nvb;
     m0 = nm0;
     n0 = nn0;
+    half = TAIL && nhalf_t;
   }
 }
 
@@ -1159,8 +1216,11 @@ int launch_gemm_ring(const GemmParams& p, hipStream_t st) {
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
   if (!(attr_devices.load(std::memory_order_acquire) & dev_bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ring_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       mi355_set_error("gemm: cannot reserve %d B of LDS: %s", LDS, hipGetErrorString(e));
       return MI355_EHIP;
@@ -1170,8 +1230,13 @@ int launch_gemm_ring(const GemmParams& p, hipStream_t st) {
   const int tiles_m = (p.M + 255) / 256, tiles_n = (p.N + 255) / 256;
   GemmParams q = p;
   q.group = tiles_n <= 16 ? 2 : 8;
-  dim3 grid((unsigned)min(tiles_m * tiles_n, resident_workgroups(LDS))), block(512);
-  hipLaunchKernelGGL(gemm_ring_kernel, grid, block, LDS, st, q);
+  const int nwg = tiles_m * tiles_n, wgs = min(nwg, resident_workgroups(LDS));
+  // a partial last round that leaves at least half of the workgroups idle is run as half tiles
+  const int tail = nwg % wgs;
+  q.split_from = (tail > 0 && 2 * tail <= wgs) ? nwg - tail : nwg;
+  dim3 grid((unsigned)wgs), block(512);
+  if (q.split_from < nwg) hipLaunchKernelGGL(gemm_ring_kernel<true>, grid, block, LDS, st, q);
+  else hipLaunchKernelGGL(gemm_ring_kernel<false>, grid, block, LDS, st, q);
   MI355_CHECK_LAUNCH("gemm_ring");
   return MI355_OK;
 }
@@ -1280,6 +1345,15 @@ int build_params(const mi355_linear_args* a, GemmParams& p) {
   return MI355_OK;
 }
 
+// the ring kernel addresses its operands with 32-bit byte offsets from their bases
+bool ring_offsets_fit(const GemmParams& p) {
+  int64_t last_row = p.M - 1;
+  if (p.a_map.rows_per_batch > 0)
+    last_row = (last_row / p.a_map.rows_per_batch) * p.a_map.batch_rows + p.a_map.row_offset +
+               p.a_map.rows_per_batch - 1;
+  return (last_row + 1) * p.lda_b < (1ll << 32) && (int64_t)p.N * p.ldw_b < (1ll << 32);
+}
+
 int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hipStream_t st) {
   if (!big && !block_scale && !p.out_f16 && use_narrow_tile(p.M, p.N))
     return fp8 ? launch_gemm<1, 4, 1, 1, 2, false, false, true>(p, st)
@@ -1298,7 +1372,7 @@ int dispatch_gemm(const GemmParams& p, bool fp8, bool block_scale, bool big, hip
   if (fp8) {
     // big tiles through the five-slot ring (same bits as the two-stage kernel, which remains for
     // a single K tile): 3-5 % less time per GEMM, whole step 192.2 -> 188.5 ms in a same-box A/B
-    if (big && p.ktiles >= 2) return launch_gemm_ring(p, st);
+    if (big && p.ktiles >= 2 && ring_offsets_fit(p)) return launch_gemm_ring(p, st);
     return big ? launch_gemm<1, 4, 2, 2, 4, false, false, true>(p, st)
                : launch_gemm<1, 2, 2, 2, 2, false, false, true>(p, st);
   }

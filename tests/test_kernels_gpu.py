@@ -189,6 +189,29 @@ def test_fp8_scaled_mm_big_tiles_through_the_ring(device, K):
         assert torch.equal(part, out[r0:r0 + rows]), (K, r0)
 
 
+@pytest.mark.parametrize("M,N", [(22 * 256, 3072), (22 * 256 + 5, 3080), (18432, 3072)])
+def test_ring_gemm_partial_last_round_as_half_tiles(device, M, N):
+    """More tiles than workgroups with a short last round (264, 299 and 864 tiles on 256 CUs):
+    the tail runs as 256 x 128 half tiles.  Same MFMAs per output element: bit-equal to the
+    small-tile kernel on row slices, and right against the oracle."""
+    K = 384
+    a = (torch.randn(M, K, generator=g(71)) * 3).clamp(-448, 448).to(FP8)
+    w = (torch.randn(N, K, generator=g(72)) * 3).clamp(-448, 448).to(FP8)
+    sa = torch.rand(M, generator=g(73)) * 0.02 + 1e-3
+    sb = torch.rand(N, generator=g(74)) * 0.02 + 1e-3
+    b = torch.randn(N, generator=g(75)).bfloat16()
+    ad, wd, sad, sbd, bd = (t.to(device) for t in (a, w, sa, sb, b))
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=device)
+    _C.fp8_scaled_mm(ad, wd, sad, sbd, bd, out)
+    if M <= 6000:
+        _gemm_close(out, ops.fp8_scaled_mm(a, w, sa, sb, b))
+    for r0 in range(0, M, 2048):             # <= 8 x 13 tiles per slice: the small-tile path
+        rows = min(2048, M - r0)
+        part = torch.empty(rows, N, dtype=torch.bfloat16, device=device)
+        _C.fp8_scaled_mm(ad[r0:r0 + rows], wd, sad[r0:r0 + rows], sbd, bd, part)
+        assert torch.equal(part.view(torch.int16), out[r0:r0 + rows].view(torch.int16)), (M, N, r0)
+
+
 @pytest.mark.parametrize("gelu", [False, True])
 def test_ring_gemm_with_row_maps_gate_and_half_columns(device, gelu):
     """The ring kernel behind the fused epilogues: joint-buffer row maps whose batches do not end
