@@ -68,6 +68,13 @@ if mode == "gelu":
         for act in (0, 1):
             print(f"act={act}", end="  ")
             bench(fp8, M, N, K, act=act)
+if mode == "shape":
+    # K = 3072 (24 K tiles per output tile): does the time per round of 256 tiles depend on M, N?
+    for M in (16384, 16640, 18432, 20480):
+        for N in (8192, 9216, 9472, 12288):
+            t = (M // 256) * (N // 256)
+            print(f"tiles {t} = {t / 256:.3f} rounds", end="  ", flush=True)
+            bench(True, M, N, 3072)
 if mode == "ksweep":
     # 1024 big tiles = 4 full rounds on 256 CUs; time is linear in K: the slope is the K loop's
     # cost per 128-byte K tile, the intercept what a tile costs outside it (epilogue, seams)
