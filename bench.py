@@ -592,9 +592,15 @@ def main():
                 "fp8-block": ", false, false, false>"}[args.mode]
         kernels = json.load(open(pmc))["kernels"]
         # the plain fp8 form runs as gemm_ring_kernel; older summaries hold the two-stage kernel
-        cands = (["gemm_ring_kernel"] if args.mode == "fp8" else []) + [key + tail, key + ", false" + tail]
-        name = next(k for k in cands if k in kernels)
-        roofline["traffic"] = kernels[name]["traffic_bytes_per_launch"]
+        cands = [key + tail, key + ", false" + tail]
+        # (as two instantiations, with and without a half-tile tail: their launches together)
+        ring = [v for k, v in kernels.items() if k.startswith("gemm_ring_kernel")] if args.mode == "fp8" else []
+        if ring:
+            roofline["traffic"] = (sum(v["traffic_bytes_per_launch"] * v["dispatches"] for v in ring)
+                                   / sum(v["dispatches"] for v in ring))
+        else:
+            name = next(k for k in cands if k in kernels)
+            roofline["traffic"] = kernels[name]["traffic_bytes_per_launch"]
         roofline["traffic_unit"] = "bytes per launch at the L2 memory side (2*FETCH_SIZE + WRITE_SIZE)"
         roofline["traffic_source"] = os.path.relpath(pmc, ROOT)
         roofline["algorithmic_bytes_per_launch"] = d["bytes"] / d["n"]
