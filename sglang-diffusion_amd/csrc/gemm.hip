@@ -199,17 +199,42 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // ia * 16 + 4 * (l >> 4) .. + 3.  Element arithmetic, rounding points and the store phase are
 // those of gemm_epilogue; only the way a round's [32][64] image is written differs (8 bytes
 // per lane and block instead of 16 after an exchange).
-template <int DT, int WAVES_M, int WAVES_N, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc)[TN * 2][TM * 2],
-                                                unsigned char* scratch, const float* sb_l,
-                                                const float* sa_l, const unsigned short* bias_l,
-                                                int m0, int n0, int wave, int lane) {
+//
+// This code runs with the matrix pipe idle (4-5 us of a 40-us tile at K = 3072), and what it
+// costs is instruction issue and exposed LDS latency, not bytes: without its global stores it
+// takes the same time.  Hence MODE: what a launch does NOT use (activation, half-format column
+// range, gate / residual) is compiled out of its copy, so that a round is one basic block in
+// which the table reads can be scheduled ahead of their use; and the addresses of a round's LDS
+// image are formed once per tile (the chunk swizzle is an XOR with a per-lane constant, so a
+// block's address is one of four per-lane values plus an immediate).
+enum : int { EPI_GENERAL = 0, EPI_PLAIN = 1, EPI_ACT = 2, EPI_F16 = 3, EPI_GATE = 4 };
+
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN, int MODE>
+__device__ __forceinline__ void gemm_epilogue16_mode(const GemmParams& p,
+                                                     f32x4 (&acc)[TN * 2][TM * 2],
+                                                     unsigned char* scratch, const float* sb_l,
+                                                     const float* sa_l, const unsigned short* bias_l,
+                                                     int m0, int n0, int wave, int lane) {
   static_assert(TN % 2 == 0, "rounds cover two 32-channel blocks");
+  constexpr bool ANY = MODE == EPI_GENERAL;
+  const bool gelu = ANY ? p.act == MI355_ACT_GELU_TANH : MODE == EPI_ACT;
+  const bool gated = ANY ? p.gate != nullptr : MODE == EPI_GATE;
   const int wm = wave % WAVES_M;
   const int wn = wave / WAVES_M;
   const int l16 = lane & 15;
   const int q = lane >> 4;
   const int lc = lane & 7, lr = lane >> 3;
+  // image of a round: row r (32 rows) is 128 bytes = 8 chunks of 8 channels, chunk c at
+  // (c ^ (r & 7)) * 16.  Block (i2, a, b) puts the lane's 4 channels into row b * 16 + l16,
+  // chunk i2 * 4 + a * 2 + (q >> 1), half (q & 1): the chunk is (i2 * 4 + a * 2) XOR (q >> 1),
+  // so its swizzled position is a per-lane constant XOR (i2 * 4 + a * 2)
+  unsigned char* wr[4];
+  {
+    const int t = ((q >> 1) ^ (l16 & 7)) << 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wr[c] = scratch + l16 * 128 + (q & 1) * 8 + (t ^ (c << 5));
+  }
+  const unsigned char* rd = scratch + lr * 128 + ((lc ^ lr) << 4);
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     float sam[2] = {1.f, 1.f};
@@ -218,14 +243,57 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
       sam[1] = sa_l[wm * TM * 32 + j * 32 + 16 + l16];
     }
     const int mw = m0 + wm * TM * 32 + j * 32;
+    // Output (and gate) rows of this 32-row block.  mw is wave-uniform, so the batch a row falls
+    // into is found with ONE division per block when a batch has at least 32 rows (the block then
+    // touches two batches at most); a per-row division otherwise.  Rows past the end of the
+    // matrix take the last row's addresses (their loads are issued, their stores are not): the
+    // block's first row is clamped like its other rows, so that every row lies in the first
+    // row's batch or the next.
+    const int mwc = min(mw, p.M - 1);
+    int orow[4];  // output / residual row of store `it` (32-bit: rows, not offsets, stay live)
+    const unsigned gr = gated ? (unsigned)p.gate_rows : 1u;
+    const unsigned gb0 = gr >= 32 ? (unsigned)mwc / gr : 0u;
+    auto gate_row = [&](int it) {  // element offset of the gate row of store `it`
+      const unsigned mc = (unsigned)min(mw + it * 8 + lr, p.M - 1);
+      const unsigned b = gr >= 32 ? gb0 + (mc >= (gb0 + 1) * gr ? 1u : 0u) : mc / gr;
+      return (int64_t)b * p.ldg;
+    };
+    {
+      const unsigned rpb = (unsigned)p.o_map.rows_per_batch;
+      const unsigned ob0 = rpb >= 32 ? (unsigned)mwc / rpb : 0u;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int mc = min(mw + it * 8 + lr, p.M - 1);  // rows past the end: the last row's address
+        if (rpb == 0) {
+          orow[it] = mc;
+        } else if (rpb >= 32) {
+          const unsigned b = ob0 + ((unsigned)mc >= (ob0 + 1) * rpb ? 1u : 0u);
+          orow[it] = (int)(b * (unsigned)p.o_map.batch_rows + (unsigned)p.o_map.row_offset +
+                           ((unsigned)mc - b * rpb));
+        } else {
+          orow[it] = (int)map_row32(mc, (int)rpb, p.o_map.batch_rows, p.o_map.row_offset);
+        }
+      }
+    }
 #pragma unroll
     for (int ip = 0; ip < TN / 2; ++ip) {
+      const int n8 = n0 + wn * TN * 32 + ip * 64 + lc * 8;
+      const bool nok = n8 < p.N;
+      const int n8c = min(n8, p.N - 8);  // N is a multiple of 8
+      // the residual of this round's four stores (from memory) is requested before the round's
+      // arithmetic, the gate (a few rows, cached) before its trip through LDS
+      u32x4 gv[4], rv[4];
+      if (gated) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          rv[it] = *reinterpret_cast<const u32x4*>(p.residual + (int64_t)orow[it] * p.ldo + n8c);
+      }
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) {
         const int i = 2 * ip + i2;
         // wave-uniform: the half-format column range is 32-aligned
         const int nblk = n0 + wn * TN * 32 + i * 32;
-        const bool as_f16 = nblk >= p.f16_begin && nblk < p.f16_end;
+        const bool as_f16 = (ANY || MODE == EPI_F16) && nblk >= p.f16_begin && nblk < p.f16_end;
         float amax = 0.f;  // largest |value| of this 32-row x 32-channel block (half columns)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -246,7 +314,7 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
               else v += bsv[e];
               y[e] = v;
             }
-            if (p.act == MI355_ACT_GELU_TANH) {
+            if (gelu) {
               const f32x2 g0 = gelu_tanh_f2(f32x2{rbf(y[0]), rbf(y[1])});
               const f32x2 g1 = gelu_tanh_f2(f32x2{rbf(y[2]), rbf(y[3])});
               y[0] = g0[0];
@@ -262,43 +330,55 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc
             } else {
               pk = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
             }
-            const int row = b * 16 + l16;
-            const int chunk = i2 * 4 + a * 2 + (q >> 1);
-            *reinterpret_cast<u32x2*>(scratch + row * 128 + ((chunk ^ (row & 7)) << 4) +
-                                      (q & 1) * 8) = pk;
+            *reinterpret_cast<u32x2*>(wr[i2 * 2 + a] + b * 16 * 128) = pk;
           }
         }
         if (as_f16) note_f16_block(p.f16_counters, group_max<64>(amax), lane);
+        if (gated && i2 == 0) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            gv[it] = *reinterpret_cast<const u32x4*>(p.gate + gate_row(it) + n8c);
+        }
       }
-      const int n8 = n0 + wn * TN * 32 + ip * 64 + lc * 8;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + lr;
-        const int m = mw + row;
-        u32x4 o = *reinterpret_cast<const u32x4*>(scratch + row * 128 + ((lc ^ (row & 7)) << 4));
-        if (m < p.M && n8 < p.N) {
-          const int64_t orow =
-              map_row32(m, (int)p.o_map.rows_per_batch, p.o_map.batch_rows, p.o_map.row_offset) *
-              p.ldo;
-          if (p.gate) {
-            const int64_t grow = (int64_t)((unsigned)m / (unsigned)p.gate_rows) * p.ldg;
-            const u32x4 gv = *reinterpret_cast<const u32x4*>(p.gate + grow + n8);
-            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.residual + orow + n8);
+        u32x4 o = *reinterpret_cast<const u32x4*>(rd + it * 8 * 128);
+        if (gated) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float y0 = __uint_as_float(o[e] << 16), y1 = __uint_as_float(o[e] & 0xffff0000u);
-              const float g0 = __uint_as_float(gv[e] << 16),
-                          g1 = __uint_as_float(gv[e] & 0xffff0000u);
-              const float r0 = __uint_as_float(rv[e] << 16),
-                          r1 = __uint_as_float(rv[e] & 0xffff0000u);
-              o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
-            }
+          for (int e = 0; e < 4; ++e) {
+            const float y0 = __uint_as_float(o[e] << 16), y1 = __uint_as_float(o[e] & 0xffff0000u);
+            const float g0 = __uint_as_float(gv[it][e] << 16),
+                        g1 = __uint_as_float(gv[it][e] & 0xffff0000u);
+            const float r0 = __uint_as_float(rv[it][e] << 16),
+                        r1 = __uint_as_float(rv[it][e] & 0xffff0000u);
+            o[e] = pack_bf2(r0 + rbf(g0 * y0), r1 + rbf(g1 * y1));
           }
-          __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(p.out + orow + n8));
         }
+        if (mw + it * 8 + lr < p.M && nok)
+          __builtin_nontemporal_store(
+              o, reinterpret_cast<u32x4*>(p.out + (int64_t)orow[it] * p.ldo + n8));
       }
     }
   }
+}
+
+template <int DT, int WAVES_M, int WAVES_N, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4 (&acc)[TN * 2][TM * 2],
+                                                unsigned char* scratch, const float* sb_l,
+                                                const float* sa_l, const unsigned short* bias_l,
+                                                int m0, int n0, int wave, int lane) {
+  // wave-uniform (kernel arguments): one copy of the epilogue per combination a Flux step uses
+  const bool gelu = p.act == MI355_ACT_GELU_TANH, halfcols = p.f16_end > p.f16_begin,
+             gated = p.gate != nullptr;
+#define MI355_EPI(MODE)                                                                          \
+  gemm_epilogue16_mode<DT, WAVES_M, WAVES_N, TM, TN, MODE>(p, acc, scratch, sb_l, sa_l, bias_l, m0, \
+                                                           n0, wave, lane)
+  if (!gelu && !halfcols && !gated) MI355_EPI(EPI_PLAIN);
+  else if (gelu && !halfcols && !gated) MI355_EPI(EPI_ACT);
+  else if (halfcols && !gelu && !gated) MI355_EPI(EPI_F16);
+  else if (gated && !gelu && !halfcols) MI355_EPI(EPI_GATE);
+  else MI355_EPI(EPI_GENERAL);
+#undef MI355_EPI
 }
 
 // accumulator tile of one wave: 32x32 blocks of 16 registers, or 16x16 blocks of 4
@@ -372,12 +452,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
   // ---- per-lane LDS-DMA source pointers (advance 128 B per K tile) ---------
   const unsigned char* src[NPIECE];
   const float* sc_src = nullptr;  // block scales: this lane's scale of the next K tile to stage
+  // (the lane id of the once-per-tile code is re-made opaque where it is used: what the compiler
+  // would otherwise compute once in front of the tile loop and keep in registers across the K
+  // loops does not fit beside the accumulators and fragments)
+  auto opaque = [](int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
   auto set_src = [&](int m0, int n0) {
+    const int ln = opaque(lane);
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
       const int piece = wave + i * NW;
-      const int row = piece * 8 + (lane >> 3);  // row inside [X tile | W tile]
-      const int pc = lane & 7;
+      const int row = piece * 8 + (ln >> 3);  // row inside [X tile | W tile]
+      const int pc = ln & 7;
       const int lc = pc ^ ((row >> 1) & 7);
       if (piece < BM / 8) {
         int64_t gmrow = m0 + row;
@@ -796,10 +884,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmPara
     __syncthreads();  // tables visible
     if constexpr (MF16)
       gemm_epilogue16<DT, WAVES_M, WAVES_N, TM, TN>(p, acc, area + wave * SCRATCH_WAVE, sb_l, sa_l,
-                                                    bias_l, em0, en0, wave, lane);
+                                                    bias_l, em0, en0, wave, opaque(lane));
     else
       gemm_epilogue<DT, WAVES_M, WAVES_N, TM, TN, BLOCKSCALE, OUT16>(
-          p, acc, area + wave * SCRATCH_WAVE, sb_l, sa_l, bias_l, em0, en0, wave, lane);
+          p, acc, area + wave * SCRATCH_WAVE, sb_l, sa_l, bias_l, em0, en0, wave, opaque(lane));
     if (!more) break;
     vb = nvb;
   }

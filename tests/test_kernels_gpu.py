@@ -283,9 +283,13 @@ def test_linear_bf16_vs_oracle(device, M, N, K, act):
     assert_close_bf16(out, ref, rel=1e-3, what="linear_bf16")
 
 
-def test_linear_ex_rowmaps_gate_residual(device):
-    """Joint-buffer row maps + fused gate/residual epilogue == separate eager ops."""
-    B, Ti, Tt, D, N = 2, 96, 32, 256, 384
+@pytest.mark.parametrize("B,Ti", [(2, 96), (1, 96), (1, 100), (3, 45)])
+def test_linear_ex_rowmaps_gate_residual(device, B, Ti):
+    """Joint-buffer row maps + fused gate/residual epilogue == separate eager ops.  One batch
+    whose rows end inside a tile: the tile's row blocks past the end take clamped addresses for
+    the residual and gate they prefetch, in the batch of the LAST row; batches shorter than a
+    32-row block take the per-row division."""
+    Tt, D, N = 32, 256, 384
     S = Ti + Tt
     x = torch.randn(B * S, D, generator=g(31)).bfloat16()       # joint activations
     w = (torch.randn(N, D, generator=g(32)) * D ** -0.5).bfloat16()

@@ -5,7 +5,8 @@ device array; this script builds it into tools/probes/bin/libmi355dit_timing.so 
 product library), runs one launch per shape and prints per-phase medians, the clock inside the
 K loop and how far apart the workgroups of a round are.  Extra compiler flags after `build`
 select ablations of the ring kernel (timing only, the results are wrong): -DABL_RING_NOMFMA
-(refill + barrier + fragment reads alone), -DABL_RING_NODMA (no refill).
+(refill + barrier + fragment reads alone), -DABL_RING_NODMA (no refill), -DABL_EPI_NOSTORE (the
+epilogues without their global stores).
 
     python tools/probes/gemm_phase_timing.py build      # here, no GPU
     python tools/probes/gemm_phase_timing.py run         # on the GPU box
@@ -95,6 +96,10 @@ def build():
     if (slot >= 0) return;
 #endif
     __builtin_amdgcn_global_load_lds(""")
+    # -DABL_EPI_NOSTORE: the epilogues without their global stores (what the transposition and
+    # the arithmetic cost alone; a tile's 128 KiB leave every CU at the same moment otherwise)
+    st = "__builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(p.out + orow + n8));"
+    rep(st, "\n#ifdef ABL_EPI_NOSTORE\n          if (p.M < 0)\n#endif\n          " + st, count=s.count(st))
     os.makedirs("/tmp/gemm_timing", exist_ok=True)
     src = "/tmp/gemm_timing/gemm_timing.hip"
     open(src, "w").write(s)
@@ -140,8 +145,22 @@ def run():
             sa = sb = None
         bias = torch.randn(N, device=dev).bfloat16()
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        # TIMING_MODE: which epilogue the launches use (plain | act | f16 | gate)
+        mode = os.environ.get("TIMING_MODE", "plain")
+        extra = {}
+        if mode == "act":
+            extra = dict(act=1)
+        elif mode == "f16":
+            extra = dict(f16_cols=(N // 3 * 2, N))
+        elif mode == "gate":
+            gate = torch.randn(4, N, device=dev).bfloat16()
+            out.normal_()
+            extra = dict(residual=out, gate=gate, ldg=gate.stride(0), gate_rows=M // 4)
         for _ in range(int(os.environ.get("TIMING_WARM", "40"))):
-            _C.linear_ex(a, w, out, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, sa=sa, sb=sb, bias=bias, fp8=fp8)
+            _C.linear_ex(a, w, out, M=M, N=N, K=K, lda=K, ldw=K, ldo=N, sa=sa, sb=sb, bias=bias, fp8=fp8,
+                         **extra)
+        if mode == "f16":
+            _C.f16_range_status(reset=True)
         torch.cuda.synchronize()
         host = np.zeros(NWG * MAXT * 4, dtype=np.uint64)
         rc = lib.mi355_dbg_stamps(host.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)))
