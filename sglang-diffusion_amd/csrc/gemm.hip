@@ -235,51 +235,73 @@ __device__ __forceinline__ void gemm_epilogue16_mode(const GemmParams& p,
     for (int c = 0; c < 4; ++c) wr[c] = scratch + l16 * 128 + (q & 1) * 8 + (t ^ (c << 5));
   }
   const unsigned char* rd = scratch + lr * 128 + ((lc ^ lr) << 4);
+  // Per-row and per-channel operands come from LDS tables, and a table read behind a write to
+  // the image cannot be moved in front of it by the compiler (both are LDS): they are read where
+  // no image write is pending -- the token scales of the wave's rows once, a 64-channel
+  // column block's scales and biases at the top of the block, for both of its 32-row rounds.
+  float sam[TM][2];
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    float sam[2] = {1.f, 1.f};
+    sam[j][0] = sam[j][1] = 1.f;
     if constexpr (DT == 1) {
-      sam[0] = sa_l[wm * TM * 32 + j * 32 + l16];
-      sam[1] = sa_l[wm * TM * 32 + j * 32 + 16 + l16];
+      sam[j][0] = sa_l[wm * TM * 32 + j * 32 + l16];
+      sam[j][1] = sa_l[wm * TM * 32 + j * 32 + 16 + l16];
     }
-    const int mw = m0 + wm * TM * 32 + j * 32;
-    // Output (and gate) rows of this 32-row block.  mw is wave-uniform, so the batch a row falls
-    // into is found with ONE division per block when a batch has at least 32 rows (the block then
-    // touches two batches at most); a per-row division otherwise.  Rows past the end of the
-    // matrix take the last row's addresses (their loads are issued, their stores are not): the
-    // block's first row is clamped like its other rows, so that every row lies in the first
-    // row's batch or the next.
-    const int mwc = min(mw, p.M - 1);
-    int orow[4];  // output / residual row of store `it` (32-bit: rows, not offsets, stay live)
-    const unsigned gr = gated ? (unsigned)p.gate_rows : 1u;
-    const unsigned gb0 = gr >= 32 ? (unsigned)mwc / gr : 0u;
-    auto gate_row = [&](int it) {  // element offset of the gate row of store `it`
-      const unsigned mc = (unsigned)min(mw + it * 8 + lr, p.M - 1);
-      const unsigned b = gr >= 32 ? gb0 + (mc >= (gb0 + 1) * gr ? 1u : 0u) : mc / gr;
-      return (int64_t)b * p.ldg;
-    };
-    {
-      const unsigned rpb = (unsigned)p.o_map.rows_per_batch;
-      const unsigned ob0 = rpb >= 32 ? (unsigned)mwc / rpb : 0u;
+  }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int mc = min(mw + it * 8 + lr, p.M - 1);  // rows past the end: the last row's address
-        if (rpb == 0) {
-          orow[it] = mc;
-        } else if (rpb >= 32) {
-          const unsigned b = ob0 + ((unsigned)mc >= (ob0 + 1) * rpb ? 1u : 0u);
-          orow[it] = (int)(b * (unsigned)p.o_map.batch_rows + (unsigned)p.o_map.row_offset +
-                           ((unsigned)mc - b * rpb));
-        } else {
-          orow[it] = (int)map_row32(mc, (int)rpb, p.o_map.batch_rows, p.o_map.row_offset);
+  for (int ip = 0; ip < TN / 2; ++ip) {
+    // (with gate / residual in flight the registers do not reach: that copy reads them in place)
+    constexpr bool TABLES_AHEAD = MODE != EPI_GATE && MODE != EPI_GENERAL;
+    f32x4 sbv[4];
+    u32x2 bb[4];
+    auto read_tables = [&](int c) {  // c = i2 * 2 + a: 16 channels
+      const int nl = wn * TN * 32 + ip * 64 + c * 16 + 4 * q;
+      sbv[c] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if constexpr (DT == 1) sbv[c] = *reinterpret_cast<const f32x4*>(sb_l + nl);
+      bb[c] = *reinterpret_cast<const u32x2*>(bias_l + nl);
+    };
+    if constexpr (TABLES_AHEAD) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) read_tables(c);
+    }
+    const int n8 = n0 + wn * TN * 32 + ip * 64 + lc * 8;
+    const bool nok = n8 < p.N;
+    const int n8c = min(n8, p.N - 8);  // N is a multiple of 8
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int mw = m0 + wm * TM * 32 + j * 32;
+      // Output (and gate) rows of this 32-row block.  mw is wave-uniform, so the batch a row
+      // falls into is found with ONE division per block when a batch has at least 32 rows (the
+      // block then touches two batches at most); a per-row division otherwise.  Rows past the
+      // end of the matrix take the last row's addresses (their loads are issued, their stores
+      // are not): the block's first row is clamped like its other rows, so that every row lies
+      // in the first row's batch or the next.
+      const int mwc = min(mw, p.M - 1);
+      int orow[4];  // output / residual row of store `it` (32-bit: rows, not offsets, stay live)
+      const unsigned gr = gated ? (unsigned)p.gate_rows : 1u;
+      const unsigned gb0 = gr >= 32 ? (unsigned)mwc / gr : 0u;
+      auto gate_row = [&](int it) {  // element offset of the gate row of store `it`
+        const unsigned mc = (unsigned)min(mw + it * 8 + lr, p.M - 1);
+        const unsigned b = gr >= 32 ? gb0 + (mc >= (gb0 + 1) * gr ? 1u : 0u) : mc / gr;
+        return (int64_t)b * p.ldg;
+      };
+      {
+        const unsigned rpb = (unsigned)p.o_map.rows_per_batch;
+        const unsigned ob0 = rpb >= 32 ? (unsigned)mwc / rpb : 0u;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int mc = min(mw + it * 8 + lr, p.M - 1);
+          if (rpb == 0) {
+            orow[it] = mc;
+          } else if (rpb >= 32) {
+            const unsigned b = ob0 + ((unsigned)mc >= (ob0 + 1) * rpb ? 1u : 0u);
+            orow[it] = (int)(b * (unsigned)p.o_map.batch_rows + (unsigned)p.o_map.row_offset +
+                             ((unsigned)mc - b * rpb));
+          } else {
+            orow[it] = (int)map_row32(mc, (int)rpb, p.o_map.batch_rows, p.o_map.row_offset);
+          }
         }
       }
-    }
-#pragma unroll
-    for (int ip = 0; ip < TN / 2; ++ip) {
-      const int n8 = n0 + wn * TN * 32 + ip * 64 + lc * 8;
-      const bool nok = n8 < p.N;
-      const int n8c = min(n8, p.N - 8);  // N is a multiple of 8
       // the residual of this round's four stores (from memory) is requested before the round's
       // arithmetic, the gate (a few rows, cached) before its trip through LDS
       u32x4 gv[4], rv[4];
@@ -297,20 +319,18 @@ __device__ __forceinline__ void gemm_epilogue16_mode(const GemmParams& p,
         float amax = 0.f;  // largest |value| of this 32-row x 32-channel block (half columns)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          const int nl = wn * TN * 32 + i * 32 + a * 16 + 4 * q;
-          f32x4 sbv = f32x4{1.f, 1.f, 1.f, 1.f};
-          if constexpr (DT == 1) sbv = *reinterpret_cast<const f32x4*>(sb_l + nl);
-          const u32x2 bb = *reinterpret_cast<const u32x2*>(bias_l + nl);
+          const int c = i2 * 2 + a;
+          if constexpr (!TABLES_AHEAD) read_tables(c);
           const f32x4 bsv =
-              f32x4{__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u),
-                    __uint_as_float(bb[1] << 16), __uint_as_float(bb[1] & 0xffff0000u)};
+              f32x4{__uint_as_float(bb[c][0] << 16), __uint_as_float(bb[c][0] & 0xffff0000u),
+                    __uint_as_float(bb[c][1] << 16), __uint_as_float(bb[c][1] & 0xffff0000u)};
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
             float y[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float v = acc[i * 2 + a][j * 2 + b][e];
-              if constexpr (DT == 1) v = fmaf(v * sam[b], sbv[e], bsv[e]);
+              if constexpr (DT == 1) v = fmaf(v * sam[j][b], sbv[c][e], bsv[e]);
               else v += bsv[e];
               y[e] = v;
             }
@@ -330,7 +350,7 @@ __device__ __forceinline__ void gemm_epilogue16_mode(const GemmParams& p,
             } else {
               pk = u32x2{pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3])};
             }
-            *reinterpret_cast<u32x2*>(wr[i2 * 2 + a] + b * 16 * 128) = pk;
+            *reinterpret_cast<u32x2*>(wr[c] + b * 16 * 128) = pk;
           }
         }
         if (as_f16) note_f16_block(p.f16_counters, group_max<64>(amax), lane);
