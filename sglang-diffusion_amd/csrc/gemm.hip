@@ -1415,6 +1415,13 @@ int build_params(const mi355_linear_args* a, GemmParams& p) {
   if (a->fp8) MI355_REQUIRE(a->sa && a->sb, "fp8 linear: scales missing");
   MI355_REQUIRE(!a->block_scale || (a->fp8 && a->K % 128 == 0),
                 "linear: block scales need the fp8 path and K %% 128 == 0");
+  // the epilogues keep the mapped output row of a store as a 32-bit number
+  if (a->o_map.rows_per_batch > 0 && a->M > 0) {
+    const int64_t last = ((a->M - 1) / a->o_map.rows_per_batch) * a->o_map.batch_rows +
+                         a->o_map.row_offset + a->o_map.rows_per_batch - 1;
+    MI355_REQUIRE(a->o_map.batch_rows >= 0 && a->o_map.row_offset >= 0 && last < (1ll << 31),
+                  "linear: output row map reaches row %ld, beyond 2^31", (long)last);
+  }
   p.a = (const unsigned char*)a->a;
   p.w = (const unsigned char*)a->w;
   p.sa = a->sa;
