@@ -314,6 +314,23 @@ def test_linear_ex_rowmaps_gate_residual(device, B, Ti):
     assert rel_l2(got[:, Tt:], exp[:, Tt:]) <= 1e-3
 
 
+def test_linear_ex_random_shapes(device):
+    """tools/probes/gemm_fuzz.py: random M / N / K, batch geometry of the row maps and epilogue
+    feature sets through every tile class, against an fp32 rendering, with sentinel rows in the
+    gaps of the joint buffer."""
+    import importlib.util
+    import os
+    import random
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probes",
+                        "gemm_fuzz.py")
+    spec = importlib.util.spec_from_file_location("gemm_fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = random.Random(11)
+    bad = [i for i in range(80) if not mod.one(rng, i)]
+    assert not bad, bad
+
+
 def test_linear_ex_block_scaled_epilogues(device):
     """The block-scaled GEMM behind the fused epilogues (bias after the bf16 cast, GELU, joint
     row maps with group scales indexed by the mapped row, gate/residual, half columns) gives
