@@ -149,9 +149,11 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float p = (kKappa * x) * x;
   const float u = kBeta * fmaf(p, x, x);
   const float e = __builtin_amdgcn_exp2f(fabsf(u) * -2.8853900817779268f);  // exp(-2|u|)
-  const float d = (2.0f * e) * __builtin_amdgcn_rcpf(1.0f + e);
-  const float th = copysignf(1.0f - d, u);
-  return (0.5f * x) * (1.0f + th);
+  // (1 - d) / 2 with d = 2e / (1 + e), and (1 + tanh) / 2: the halves are exact scalings of
+  // the values in the formula above (the power of two commutes with every rounding), so
+  // x * ((1 + tanh) / 2) has the bits of (0.5 x) * (1 + tanh) with four instructions less
+  const float th_half = 0.5f + (-e) * __builtin_amdgcn_rcpf(1.0f + e);
+  return x * (0.5f + copysignf(th_half, u));
 }
 // Two values at a time: the plain multiplies / adds / fmas become packed fp32 instructions
 // (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32: two results per issue slot); exp2 and rcp stay
@@ -162,17 +164,17 @@ __device__ __forceinline__ f32x2 gelu_tanh_f2(f32x2 x) {
 #pragma clang fp contract(off)
   const f32x2 kBeta = f32x2{0.7978845608028654f, 0.7978845608028654f};
   const f32x2 kKappa = f32x2{0.044715f, 0.044715f};
-  const f32x2 one = f32x2{1.0f, 1.0f};
+  const f32x2 half = f32x2{0.5f, 0.5f};
   const f32x2 p = (kKappa * x) * x;
   const f32x2 u = kBeta * __builtin_elementwise_fma(p, x, x);
-  const f32x2 au = __builtin_elementwise_abs(u) * f32x2{-2.8853900817779268f, -2.8853900817779268f};
-  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(au[0]), __builtin_amdgcn_exp2f(au[1])};
-  const f32x2 den = one + e;
+  // |u| as a source modifier of a plain multiply (the packed form has none)
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(fabsf(u[0]) * -2.8853900817779268f),
+                        __builtin_amdgcn_exp2f(fabsf(u[1]) * -2.8853900817779268f)};
+  const f32x2 den = f32x2{1.0f, 1.0f} + e;
   const f32x2 rc = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  const f32x2 d = (f32x2{2.0f, 2.0f} * e) * rc;
-  const f32x2 omd = one - d;
-  const f32x2 th = f32x2{copysignf(omd[0], u[0]), copysignf(omd[1], u[1])};
-  return (f32x2{0.5f, 0.5f} * x) * (one + th);
+  const f32x2 th_half = half + (-e) * rc;
+  const f32x2 ths = f32x2{copysignf(th_half[0], u[0]), copysignf(th_half[1], u[1])};
+  return x * (half + ths);
 }
 __device__ __forceinline__ float silu_f(float x) {
   return x / (1.0f + __expf(-x));
